@@ -1,0 +1,140 @@
+"""Seeded input recipes shared by tests/golden/make_golden.py (build container, runs the reference) and
+by the parity tests (any box).  numpy PCG64 streams are stable across platforms; every float input is
+rounded to an fp16-representable value so fp16 and fp32 paths see identical numbers.
+"""
+import zlib
+
+import numpy as np
+
+
+def _rng(name):
+    return np.random.default_rng(zlib.crc32(name.encode()))
+
+
+def _h(x):
+    """round to fp16-representable fp32"""
+    return x.astype(np.float16).astype(np.float32)
+
+
+def region_table(rng, Bw, L, S, nreg=3, differ=True):
+    """A table shaped like encode_region_map_sp's output (encode_region_map_function.py:49-69):
+    per region r, columns cols_r get +weight_r inside the mask and -outside_r elsewhere."""
+    w = np.zeros((Bw, L, S), dtype=np.float32)
+    weights = [0.5, 0.75, 1.0, 0.25]
+    outs = [0.0, 0.25, 0.5, 0.0]
+    for r in range(nreg):
+        mask = rng.random(L) < 0.4
+        val = np.where(mask, weights[r % 4], -outs[r % 4]).astype(np.float32)
+        for c in (2 + 2 * r, 3 + 2 * r):
+            if c < S:
+                w[:, :, c] += val[None, :]
+    if differ and Bw > 1:           # exercise the b = bh // H indexing with distinct rows
+        w[1] *= 1.5
+    return w
+
+
+def attn_inputs(name, Bc, H, L, S, d, Bw=None, nrows=16):
+    rng = _rng("attn/" + name)
+    q = _h(rng.standard_normal((Bc, H, L, d)))
+    k = _h(rng.standard_normal((Bc, H, S, d)))
+    v = _h(rng.standard_normal((Bc, H, S, d)))
+    w = region_table(rng, Bc if Bw is None else Bw, L, S)
+    rows = np.sort(rng.choice(L, size=min(nrows, L), replace=False)).astype(np.int64)
+    return {"q": q, "k": k, "v": v, "w": w, "rows": rows}
+
+
+def proc_inputs():
+    rng = _rng("proc")
+    C, H, ctx, L, S = 160, 4, 96, 64, 77
+    p = {"C": C, "H": H, "ctx": ctx, "L": L, "S": S}
+    p["hidden"] = _h(rng.standard_normal((2, L, C)))
+    p["enc"] = _h(rng.standard_normal((2, S, ctx)))
+    p["wq"] = _h(rng.standard_normal((C, C)) / np.sqrt(C))
+    p["wk"] = _h(rng.standard_normal((C, ctx)) / np.sqrt(ctx))
+    p["wv"] = _h(rng.standard_normal((C, ctx)) / np.sqrt(ctx))
+    p["wk_self"] = _h(rng.standard_normal((C, C)) / np.sqrt(C))
+    p["wv_self"] = _h(rng.standard_normal((C, C)) / np.sqrt(C))
+    p["wo"] = _h(rng.standard_normal((C, C)) / np.sqrt(C))
+    p["bo"] = _h(rng.standard_normal((C,)) * 0.1)
+    p["w"] = region_table(rng, 2, L, S)
+    return p
+
+
+# ----------------------------------------------------------------------------- region encoder inputs
+_VOCAB = {}
+
+
+class FakeTokenizer:
+    """Deterministic word -> id tokenizer with the call surface encode_region_map_sp uses
+    (encode_region_map_function.py:42-47)."""
+    model_max_length = 77
+
+    @staticmethod
+    def word_id(word):
+        return 1000 + (zlib.crc32(word.encode()) % 40000)
+
+    def __call__(self, text, max_length=None, truncation=True, add_special_tokens=False, **kw):
+        ids = [self.word_id(t) for t in text.split()]
+        if add_special_tokens:
+            ids = [49406] + ids + [49407]
+        if max_length is not None and truncation:
+            ids = ids[:max_length]
+        return type("Enc", (), {"input_ids": ids})()
+
+
+def prompt_ids(prompt, S=77):
+    """[1,S] CLIP-style ids: BOS, words, EOS padding."""
+    tok = FakeTokenizer()
+    ids = [49406] + tok(prompt).input_ids
+    ids = ids[: S - 1]
+    ids = ids + [49407] * (S - len(ids))
+    return np.array([ids], dtype=np.int64)
+
+
+def rect_map(H, W, x0, y0, x1, y1):
+    """uint8 map, region = pixels < 255 (encode_region_map_function.py:49); coordinates in 64-px cells."""
+    m = np.full((H, W), 255, dtype=np.uint8)
+    m[y0 * 64:y1 * 64, x0 * 64:x1 * 64] = 0
+    return m
+
+
+def region_state_inputs():
+    cases = {}
+    P = "a photo of a red apple on a wooden table near a blue vase and a red apple"
+    N = "blurry low quality"
+    ids = [prompt_ids(N), prompt_ids(P)]
+    # 1 region, UI defaults weight 0.5 / mask_outsides 0 (app.py:1332-1336)
+    cases["r1_512"] = ({"wooden table": {"map": rect_map(512, 512, 0, 4, 8, 8), "weight": 0.5, "mask_outsides": 0.0}},
+                       ids, 512, 512, 1)
+    # 2 regions; "red apple" occurs twice in the prompt; non-zero outside penalty
+    cases["r2_512"] = ({"red apple": {"map": rect_map(512, 512, 1, 1, 4, 5), "weight": 0.5, "mask_outsides": 0.3},
+                        "blue vase": {"map": rect_map(512, 512, 5, 0, 8, 4), "weight": 0.8, "mask_outsides": 0.0}},
+                       ids, 512, 512, 1)
+    # 4 regions, two images per prompt
+    cases["r4_512_n2"] = ({"red apple": {"map": rect_map(512, 512, 0, 0, 4, 4), "weight": 0.5, "mask_outsides": 0.0},
+                           "blue vase": {"map": rect_map(512, 512, 4, 0, 8, 4), "weight": 0.5, "mask_outsides": 0.0},
+                           "wooden table": {"map": rect_map(512, 512, 0, 4, 4, 8), "weight": 0.5, "mask_outsides": 0.0},
+                           "photo": {"map": rect_map(512, 512, 4, 4, 8, 8), "weight": 0.5, "mask_outsides": 0.1}},
+                          ids, 512, 512, 2)
+    # quirk q3: an empty region (no pixel < 255) makes `== max` all-true -> whole level positive
+    cases["empty_region"] = ({"blue vase": {"map": np.full((512, 512), 255, np.uint8), "weight": 0.5, "mask_outsides": 0.2}},
+                             ids, 512, 512, 1)
+    # quirk q2: state None still yields a dict of zeros
+    cases["state_none"] = (None, ids, 512, 512, 1)
+    # text ids None -> non-dict
+    cases["ids_none"] = (None, [None, None], 512, 512, 1)
+    # map None is skipped; phrase not in the prompt prints and leaves zeros
+    cases["map_none_notfound"] = ({"red apple": {"map": None, "weight": 0.5, "mask_outsides": 0.0},
+                                   "green dragon": {"map": rect_map(512, 512, 0, 0, 8, 8), "weight": 0.5, "mask_outsides": 0.0}},
+                                  ids, 512, 512, 1)
+    # non-square 768x512 (L = 96*64 at level 0)
+    cases["r2_768x512"] = ({"red apple": {"map": rect_map(512, 768, 0, 0, 6, 8), "weight": 0.5, "mask_outsides": 0.0},
+                            "blue vase": {"map": rect_map(512, 768, 6, 2, 12, 6), "weight": 1.0, "mask_outsides": 0.5}},
+                           ids, 768, 512, 1)
+    # two prompts, per-prompt state list
+    P2 = "a green dragon flying over a red apple"
+    ids2 = [np.concatenate([prompt_ids(N), prompt_ids(N)]), np.concatenate([prompt_ids(P), prompt_ids(P2)])]
+    cases["two_prompts"] = ([{"wooden table": {"map": rect_map(512, 512, 0, 4, 8, 8), "weight": 0.5, "mask_outsides": 0.0}},
+                             {"green dragon": {"map": rect_map(512, 512, 2, 0, 6, 4), "weight": 0.6, "mask_outsides": 0.0}}],
+                            ids2, 512, 512, 1)
+    return cases

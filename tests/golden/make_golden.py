@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Capture golden vectors by running the REFERENCE's own Python in the build container.
+
+Run (build container only; /root/reference is not present on the GPU box):
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+What runs here is the reference's code, loaded from /root/reference/source/modules with
+`importlib` after inert stand-ins are registered for the third-party names it imports but that
+are absent from this image (diffusers, k_diffusion, cv2) - SURVEY.md Appendix D.  None of the
+stand-ins takes part in the arithmetic that is captured:
+
+  * attention_modify.py         -> a1 `scaled_dot_product_attention_regionstate` (:74-103),
+                                   a3 `AttnProcessor2_0.__call__` (:414-503),
+                                   a4 `AttnProcessor.__call__` + `get_attention_scores` (:39-70,:106-207)
+  * encode_region_map_function.py -> a5 `encode_region_map(_sp)` (:21-124); cv2.resize is replaced by a
+                                   block-centre sampler that is exact only for masks constant on
+                                   64-px-aligned blocks, so only such masks are captured.
+  * external_k_diffusion.py     -> a6 `DiscreteSchedule.sigma_to_t/t_to_sigma`,
+                                   `DiscreteEpsDDPMDenoiser.get_scalings/forward`, `CompVisDenoiser`
+  * `weight_func`               -> a2: the lambda text is read out of model_k_diffusion.py:967 and eval'd.
+
+Only data (seeded inputs recipe + outputs) is written; no reference source is copied.
+Inputs are produced by numpy's PCG64 `default_rng(seed)` and rounded to fp16-representable values so
+that the same bits can be regenerated on any box (tests/golden/inputs.py).
+"""
+import importlib.util
+import math
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from inputs import attn_inputs, proc_inputs, region_state_inputs, FakeTokenizer  # noqa: E402
+
+REF = "/root/reference/source/modules"
+
+
+# --------------------------------------------------------------------------- stand-ins
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def register_standins():
+    class _Logger:
+        def warning(self, *a, **k):
+            pass
+        info = debug = error = warning
+
+    class _Logging:
+        @staticmethod
+        def get_logger(name):
+            return _Logger()
+
+    noop = lambda *a, **k: None  # noqa: E731
+    _mod("diffusers", DiffusionPipeline=type("DiffusionPipeline", (), {}))
+    _mod("diffusers.utils", USE_PEFT_BACKEND=True, _get_model_file=noop, delete_adapter_layers=noop,
+         is_accelerate_available=lambda: False, logging=_Logging(), set_adapter_layers=noop,
+         set_weights_and_activate_adapters=noop, BaseOutput=type("BaseOutput", (), {}), deprecate=noop,
+         scale_lora_layers=noop, unscale_lora_layers=noop)
+    _mod("diffusers.models")
+    _mod("diffusers.models.embeddings", ImageProjection=type("ImageProjection", (), {}))
+    _mod("diffusers.models.modeling_utils", _LOW_CPU_MEM_USAGE_DEFAULT=False, load_model_dict_into_meta=noop)
+    _mod("diffusers.image_processor", IPAdapterMaskProcessor=type("IPAdapterMaskProcessor", (), {}))
+
+    # cv2.resize stand-in: samples the source at the centre of each destination cell.  For a mask
+    # that is constant on (src/dst)-sized aligned blocks every bicubic tap of the real OpenCV kernel
+    # falls inside one block, so the result is that block's value whatever the kernel: exact.
+    def _resize(img, dsize, interpolation=None):
+        w_r, h_r = dsize
+        H, W = img.shape[:2]
+        ys = np.minimum((np.arange(h_r) + 0.5) * (H / h_r), H - 1).astype(np.int64)
+        xs = np.minimum((np.arange(w_r) + 0.5) * (W / w_r), W - 1).astype(np.int64)
+        return img[ys][:, xs]
+
+    _mod("cv2", resize=_resize, INTER_CUBIC=2)
+
+    def append_dims(x, target_dims):
+        return x[(...,) + (None,) * (target_dims - x.ndim)]
+
+    def append_zero(x):
+        return torch.cat([x, x.new_zeros([1])])
+
+    kd = _mod("k_diffusion")
+    kd.sampling = _mod("k_diffusion.sampling", append_zero=append_zero)
+    kd.utils = _mod("k_diffusion.utils", append_dims=append_dims)
+
+
+def load_ref(fname):
+    spec = importlib.util.spec_from_file_location("ref_" + fname[:-3], os.path.join(REF, fname))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def ref_weight_func():
+    """The reference's own lambda, read from the default argument at model_k_diffusion.py:967."""
+    line = open(os.path.join(REF, "model_k_diffusion.py")).read().splitlines()[966]
+    m = re.search(r"weight_func\s*=\s*(lambda w, sigma, qk:[^,]+),", line)
+    assert m, line
+    return eval(m.group(1))  # noqa: S307 - evaluates the reference's one-line lambda
+
+
+# --------------------------------------------------------------------------- duck-typed Attention
+class DuckAttn:
+    """Carries exactly the attributes the reference processors touch."""
+
+    def __init__(self, p, residual_connection=False, rescale=1.0):
+        C, ctx, H = p["C"], p["ctx"], p["H"]
+        self.heads = H
+        self.scale = (C // H) ** -0.5
+        self.upcast_attention = False
+        self.upcast_softmax = False
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = residual_connection
+        self.rescale_output_factor = rescale
+        lin = lambda w, b=None: (lambda x, *a: torch.nn.functional.linear(x, w, b))  # noqa: E731
+        self.to_q = lin(torch.from_numpy(p["wq"]))
+        self.to_k = lin(torch.from_numpy(p["wk"]))
+        self.to_v = lin(torch.from_numpy(p["wv"]))
+        self.to_out = [lin(torch.from_numpy(p["wo"]), torch.from_numpy(p["bo"])), lambda x: x]
+
+    def prepare_attention_mask(self, m, *a, **k):
+        return m
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        return t.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, n, c // self.heads)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        return t.reshape(bh // self.heads, self.heads, n, d).permute(0, 2, 1, 3).reshape(bh // self.heads, n, d * self.heads)
+
+    def get_attention_scores(self, q, k, attention_mask=None):
+        s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(-1, -2),
+                          beta=0, alpha=self.scale)
+        return s.softmax(dim=-1)
+
+
+def checksum(x):
+    x = x.double()
+    return np.array([x.sum().item(), (x * x).sum().item()], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------- captures
+def capture_attention(am, wf):
+    out = {}
+    cases = [("L64_d160", 64, 160, 0.7), ("L256_d160", 256, 160, 3.25), ("L1024_d80", 1024, 80, 9.5),
+             ("L4096_d40", 4096, 40, 14.6146)]
+    for name, L, d, sigma in cases:
+        x = attn_inputs(name, Bc=2, H=8, L=L, S=77, d=d)
+        q, k, v, w = (torch.from_numpy(x[n]) for n in ("q", "k", "v", "w"))
+        sig = torch.tensor(sigma, dtype=torch.float32)
+        o = am.scaled_dot_product_attention_regionstate(q, k, v, weight_func=wf, region_state=w, sigma=sig)
+        a = (q @ k.transpose(-2, -1)) * (1 / math.sqrt(d))
+        out[name + "/sigma"] = np.float32(sigma)
+        out[name + "/std"] = np.float64(a.std().item())
+        out[name + "/checksum"] = checksum(o)
+        rows = x["rows"]
+        out[name + "/rows"] = rows
+        out[name + "/out_rows"] = o[:, :, rows, :].numpy()
+        if L <= 64:
+            out[name + "/out"] = o.numpy()
+    # std couples the rows of a group: sample-0 output must move when only sample-1's input moves
+    x = attn_inputs("L64_d160", Bc=2, H=8, L=64, S=77, d=160)
+    q, k, v, w = (torch.from_numpy(x[n]) for n in ("q", "k", "v", "w"))
+    q2 = q.clone()
+    q2[1] *= 3.0
+    sig = torch.tensor(0.7)
+    o2 = am.scaled_dot_product_attention_regionstate(q2, k, v, weight_func=wf, region_state=w, sigma=sig)
+    out["coupling/out_b0"] = o2[0].numpy()
+    # fp16 tensors on CPU (the dtype the reference runs in, app.py:271-292); sigma fp16 as at
+    # model_k_diffusion.py:1027-1029,1100
+    x = attn_inputs("L256_d160", Bc=2, H=8, L=256, S=77, d=160)
+    q, k, v = (torch.from_numpy(x[n]).half() for n in ("q", "k", "v"))
+    w = torch.from_numpy(x["w"])
+    sig = torch.tensor(3.25, dtype=torch.float16)
+    o = am.scaled_dot_product_attention_regionstate(q, k, v, weight_func=wf, region_state=w, sigma=sig)
+    a16 = (q @ k.transpose(-2, -1)) * (1 / math.sqrt(160))
+    out["fp16_L256_d160/out_rows"] = o[:, :, x["rows"], :].float().numpy()
+    out["fp16_L256_d160/std"] = np.float32(a16.std().float().item())
+    np.savez_compressed(os.path.join(HERE, "attention_core.npz"), **out)
+    print("attention_core.npz", {k: np.shape(v) for k, v in out.items()})
+
+
+def capture_processors(am, wf):
+    out = {}
+    p = proc_inputs()
+    L, S = p["L"], p["S"]
+    hs = torch.from_numpy(p["hidden"])            # [2, L, C]
+    enc = torch.from_numpy(p["enc"])              # [2, S, ctx]
+    w = {L: torch.from_numpy(p["w"])}
+    sigma = torch.tensor(2.5)
+    rp = {"region_state": w, "sigma": sigma, "weight_func": wf}
+    attn = DuckAttn(p)
+    for pname, proc in (("p2", am.AttnProcessor2_0()), ("p1", am.AttnProcessor())):
+        out[pname + "/cross_region"] = proc(attn, hs, encoder_hidden_states=enc, region_prompt=rp).numpy()
+        out[pname + "/cross_noregion"] = proc(attn, hs, encoder_hidden_states=enc).numpy()
+        rp_nd = {"region_state": torch.FloatTensor(0), "sigma": sigma, "weight_func": wf}
+        out[pname + "/cross_nondict"] = proc(attn, hs, encoder_hidden_states=enc, region_prompt=rp_nd).numpy()
+    # self-attention: encoder_hidden_states None, region_prompt present (the same kwargs reach both)
+    pself = dict(p)
+    pself["wk"], pself["wv"] = p["wk_self"], p["wv_self"]
+    attn_s = DuckAttn(pself)
+    out["p2/self"] = am.AttnProcessor2_0()(attn_s, hs, region_prompt=rp).numpy()
+    out["p1/self"] = am.AttnProcessor()(attn_s, hs, region_prompt=rp).numpy()
+    # 4-D input + residual + rescale (attention_modify.py:433-435,495-501)
+    h = int(math.isqrt(L))
+    hs4 = hs.transpose(1, 2).reshape(2, p["C"], h, h).contiguous()
+    attn_r = DuckAttn(p, residual_connection=True, rescale=2.0)
+    # note: with 4-D input the table key is hidden_states.shape[1] == C (attention_modify.py:427), so the
+    # table must be keyed by C for the region branch to find it
+    rp4 = {"region_state": {p["C"]: torch.from_numpy(p["w"])}, "sigma": sigma, "weight_func": wf}
+    out["p2/cross_region_4d_res"] = am.AttnProcessor2_0()(attn_r, hs4, encoder_hidden_states=enc, region_prompt=rp4).numpy()
+    out["p1/cross_region_4d_res"] = am.AttnProcessor()(attn_r, hs4, encoder_hidden_states=enc, region_prompt=rp4).numpy()
+    np.savez_compressed(os.path.join(HERE, "processors.npz"), **out)
+    print("processors.npz", {k: np.shape(v) for k, v in out.items()})
+
+
+def capture_region_encoder(er):
+    out = {}
+    for name, (state, ids, W, H, nimg) in region_state_inputs().items():
+        tok = FakeTokenizer()
+        pipe = types.SimpleNamespace(tokenizer=tok, unet=types.SimpleNamespace(down_blocks=[0, 1, 2, 3]),
+                                     vae_scale_factor=8, do_classifier_free_guidance=True)
+        rs = er.encode_region_map(pipe, state, width=W, height=H, num_images_per_prompt=nimg, text_ids=ids)
+        if not isinstance(rs, dict):
+            out[name + "/nondict_numel"] = np.int64(rs.numel())
+            continue
+        out[name + "/keys"] = np.array(sorted(rs.keys()), dtype=np.int64)
+        for L, t in rs.items():
+            t = t.numpy()
+            assert t.dtype == np.float32
+            nz = np.nonzero(t)
+            out[f"{name}/{L}/shape"] = np.array(t.shape, dtype=np.int64)
+            out[f"{name}/{L}/idx"] = np.stack(nz).astype(np.int32)
+            out[f"{name}/{L}/val"] = t[nz]
+    np.savez_compressed(os.path.join(HERE, "region_encoder.npz"), **out)
+    print("region_encoder.npz", len(out), "arrays")
+
+
+def capture_denoiser(ek):
+    out = {}
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2   # scaled_linear
+    alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+
+    class Inner:
+        alphas_cumprod_ = alphas_cumprod
+
+        def __init__(self):
+            self.alphas_cumprod = alphas_cumprod
+            self.calls = []
+
+        def apply_model(self, x, t, cond=None, **kw):
+            self.calls.append((x.clone(), t.clone()))
+            return torch.sin(x * 1.3) * 0.5 + 0.01 * t.reshape(-1, 1, 1, 1) / 1000.0
+
+    inner = Inner()
+    den = ek.CompVisDenoiser(inner)
+    out["alphas_cumprod"] = alphas_cumprod.numpy()
+    out["sigmas"] = den.sigmas.numpy()
+    out["log_sigmas"] = den.log_sigmas.numpy()
+    grid = torch.tensor([14.6146, 12.283, 7.0944, 3.1686, 1.0, 0.7695, 0.2480, 0.0923, 0.0292, 0.029168, 20.0, 0.01],
+                        dtype=torch.float32)
+    out["grid"] = grid.numpy()
+    out["t_of_sigma"] = torch.stack([den.sigma_to_t(s.reshape(1)) for s in grid]).reshape(-1).numpy()
+    out["t_of_sigma_quant"] = torch.stack([den.sigma_to_t(s.reshape(1), quantize=True) for s in grid]).reshape(-1).numpy()
+    c_out, c_in = den.get_scalings(grid)
+    out["c_out"], out["c_in"] = c_out.numpy(), c_in.numpy()
+    tt = torch.tensor([0.0, 0.5, 10.25, 353.8903, 998.9995, 999.0])
+    out["t_grid"] = tt.numpy()
+    out["sigma_of_t"] = den.t_to_sigma(tt).numpy()
+    out["get_sigmas_10"] = den.get_sigmas(10).numpy()
+    rng = np.random.default_rng(77)
+    x = torch.from_numpy(rng.standard_normal((2, 4, 8, 8)).astype(np.float32))
+    sig = torch.tensor([3.1686])
+    out["fwd_x"] = x.numpy()
+    out["fwd_sigma"] = sig.numpy()
+    out["fwd_out"] = den(x, sig, cond=None).numpy()
+    out["fwd_inner_x"] = inner.calls[-1][0].numpy()
+    out["fwd_inner_t"] = inner.calls[-1][1].numpy()
+    # B=2 latents with CFG duplication is a broadcast error in the reference: record it
+    try:
+        den(torch.zeros(4, 4, 8, 8), torch.tensor([1.0, 2.0]), cond=None)
+        out["b2_raises"] = np.int64(0)
+    except RuntimeError:
+        out["b2_raises"] = np.int64(1)
+    np.savez_compressed(os.path.join(HERE, "denoiser.npz"), **out)
+    print("denoiser.npz", {k: np.shape(v) for k, v in out.items()})
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    register_standins()
+    am = load_ref("attention_modify.py")
+    er = load_ref("encode_region_map_function.py")
+    ek = load_ref("external_k_diffusion.py")
+    wf = ref_weight_func()
+    capture_attention(am, wf)
+    capture_processors(am, wf)
+    capture_region_encoder(er)
+    capture_denoiser(ek)
+
+
+if __name__ == "__main__":
+    main()
