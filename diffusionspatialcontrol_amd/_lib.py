@@ -1,0 +1,71 @@
+"""ctypes binding of libdsc_hip.so (include/dsc_hip.h).  Fails loudly when the library is missing."""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DscLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libdsc_hip.so")
+
+
+def header_path():
+    return os.path.join(os.path.dirname(_HERE), "include", "dsc_hip.h")
+
+
+def declared_symbols():
+    """Every function name declared in include/dsc_hip.h."""
+    txt = open(header_path()).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsc_[a-z0-9_]+)\s*\(", txt)))
+
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+
+_SIGNATURES = {
+    "dsc_abi_version": (ctypes.c_int, []),
+    "dsc_target_arch": (ctypes.c_char_p, []),
+    "dsc_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "dsc_region_xattn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "dsc_region_xattn_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 7 + [_i64p] * 4 +
+                             [ctypes.c_float, _vp, ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, ctypes.c_size_t, _vp]),
+    "dsc_region_xattn_std": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_i64p] * 2 +
+                             [ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, _vp, ctypes.c_size_t, _vp]),
+}
+
+
+def load_library():
+    """Load libdsc_hip.so once; raise DscLibraryError (never fall back) when it is absent or stale."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise DscLibraryError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP hot path.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise DscLibraryError(f"cannot load {path}: {e}") from e
+    for name in declared_symbols():
+        if not hasattr(lib, name):
+            raise DscLibraryError(f"{path} does not export {name} (declared in include/dsc_hip.h): stale build?")
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load_library().dsc_status_string(status).decode()
+        raise DscLibraryError(f"{what} failed with status {status}: {msg}")

@@ -1,0 +1,494 @@
+// Region-biased cross-attention for gfx950 (MI355X): the kernel behind dsc_region_xattn_fwd / _std.
+//
+// Replaces the reference's op chain  q@k^T -> *scale -> std() -> w*sigma*std -> repeat_interleave -> += ->
+// softmax -> @v  (source/modules/attention_modify.py:74-103, source/app.py:1004).
+//
+// The std is GLOBAL over a std group (all heads, all rows of the group), so the work is two launches:
+//   phase 1  xattn_stats : scores on MFMA, per-workgroup (sum, sum of squares) in fp64 -> workspace partials
+//   phase 2  xattn_fwd   : every workgroup re-reduces its group's partials (a few KB, L2-resident) to the
+//                          std, recomputes its scores, adds region*sigma*std, softmax, PV, stores fp16 out
+// Nothing is zero-initialised, no atomics: results are bit-reproducible run to run.
+//
+// Decomposition (one wave = 32 query rows of one (b, h)):
+//   S^T[s, l] = K[s, :] . Q[l, :]   "swapped" product: A = K (rows s), B = Q^T, so that after the MFMA every
+//   lane owns ONE query row l = lane & 31 and half of its S key columns in registers -> the softmax row
+//   reduction is lane-local plus one exchange with lane ^ 32 (no LDS, no 5-stage shuffle tree).
+//   O^T[dd, l] = sum_s V^T[dd, s] P^T[s, l]: the fp16-packed score registers are already the B operand of this
+//   MFMA (k order permuted inside each 16-step); the A operand V^T is read from an LDS image transposed at
+//   staging time in exactly that permuted order.
+// K (zero-padded to 96 x 16*NK) and V^T are staged once per workgroup in LDS and shared by its 4 waves; the
+// fp32 region tile of a wave (32 rows x S, contiguous in HBM) is staged through LDS with coalesced loads.
+// blockIdx is mapped so that the H heads of one (b, row chunk) share an XCD: they re-read the same region
+// rows and the same 128-B lines of Q from that XCD's L2.
+#include "dsc_common.h"
+#include "dsc_hip.h"
+
+namespace {
+
+constexpr int kSMax = 96;        // key length padded to 3 MFMA row tiles
+constexpr int kSP = 100;         // V^T LDS row stride in halves: 50 dwords -> ds_read_b64 conflict-free over 32 rows
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+
+struct XattnParams {
+    const half_t* q; const half_t* k; const half_t* v; half_t* out;
+    const float* region;
+    const float* sigma_dev;
+    double* partials;            // [n_groups][npart][2]
+    float* std_out;              // optional [n_groups]
+    float sigma_host, scale;
+    int Bc, H, L, S, d, Bw, n_groups;
+    int nchunks, tiles_per_wave, npart, xcd_map;
+    long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
+    unsigned flags;
+};
+
+__device__ __forceinline__ void block_to_work(const XattnParams& p, int& b, int& h, int& chunk) {
+    const int bid = blockIdx.x;
+    int cg;
+    if (p.xcd_map) {             // (Bc * nchunks) % 8 == 0: the H heads of a chunk sit on one XCD (bid % 8)
+        const int x = bid & 7, j = bid >> 3;
+        h = j % p.H;
+        cg = (j / p.H) * 8 + x;
+    } else {
+        h = bid % p.H;
+        cg = bid / p.H;
+    }
+    b = cg / p.nchunks;
+    chunk = cg % p.nchunks;
+}
+
+// K[b, :, h, :] -> LDS image Ks[96][KP], zero outside s < S, col < d.
+template <int NK>
+__device__ __forceinline__ void stage_k(const XattnParams& p, half_t* Ks, int b, int h) {
+    constexpr int KP = 16 * NK + 8, KP8 = KP / 8;
+    const half_t* kb = p.k + b * p.ksb + h * p.ksh;
+    for (int idx = threadIdx.x; idx < kSMax * KP8; idx += kThreads) {
+        const int s = idx / KP8, c = idx - s * KP8;
+        h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (s < p.S && c * 8 < p.d) val = *reinterpret_cast<const h8_t*>(kb + s * p.kss + c * 8);
+        *reinterpret_cast<h8_t*>(Ks + s * KP + c * 8) = val;
+    }
+}
+
+// V[b, :, h, :] -> LDS image Vt[32*DM][kSP] (transposed), zero outside dd < d, s < S.
+template <int DM>
+__device__ __forceinline__ void stage_vt(const XattnParams& p, half_t* Vt, int b, int h) {
+    const half_t* vb = p.v + b * p.vsb + h * p.vsh;
+    const int d8 = p.d >> 3;
+    for (int idx = threadIdx.x; idx < p.S * d8; idx += kThreads) {
+        const int s = idx / d8, c = idx - s * d8;
+        const h8_t val = *reinterpret_cast<const h8_t*>(vb + s * p.vss + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * kSP + s] = val[j];
+    }
+    const int padrows = 32 * DM - p.d;                       // rows dd >= d
+    for (int idx = threadIdx.x; idx < padrows * kSP; idx += kThreads) Vt[p.d * kSP + idx] = (half_t)0;
+    const int padcols = kSP - p.S;                           // cols s >= S of the live rows
+    for (int idx = threadIdx.x; idx < p.d * padcols; idx += kThreads) {
+        const int dd = idx / padcols, s = p.S + (idx - dd * padcols);
+        Vt[dd * kSP + s] = (half_t)0;
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void load_q_frags(const XattnParams& p, h8_t (&qf)[NK], int b, int h, int row, int hh) {
+    const half_t* qb = p.q + b * p.qsb + h * p.qsh + (long long)row * p.qsl;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int col = 16 * ks + 8 * hh;
+        h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (col < p.d) val = *reinterpret_cast<const h8_t*>(qb + col);
+        qf[ks] = val;
+    }
+}
+
+// scores of one 32-row tile: acc[m] element i <-> s = 32m + (i & 3) + 8 (i >> 2) + 4 hh, l = lane & 31
+template <int NK, bool REF16>
+__device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, const h8_t (&qf)[NK], f16x_t (&acc)[3],
+                                       int r, int hh, float scale) {
+    constexpr int KP = 16 * NK + 8;
+    const int mt = (p.S + 31) >> 5;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+        if (m < mt) {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const h8_t kf = *reinterpret_cast<const h8_t*>(Ks + (32 * m + r) * KP + 16 * ks + 8 * hh);
+                acc[m] = mfma_32x32x16(kf, qf[ks], acc[m]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            // attention_modify.py:90 - the matmul result is an fp16 tensor, then * scale_factor rounds again
+            if (REF16) acc[m][i] = round_f16(round_f16(acc[m][i]) * scale);
+            else acc[m][i] = acc[m][i] * scale;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ phase 1
+template <int NK, bool REF16>
+__global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KP = 16 * NK + 8;
+    half_t* Ks = reinterpret_cast<half_t*>(smem);
+    double* red = reinterpret_cast<double*>(smem + kSMax * KP * 2);
+    int b, h, chunk;
+    block_to_work(p, b, h, chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    stage_k<NK>(p, Ks, b, h);
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
+    for (int t = 0; t < p.tiles_per_wave; ++t) {
+        const int l0 = (chunk * kWaves * p.tiles_per_wave + t * kWaves + wave) * 32;
+        if (l0 >= p.L) break;
+        const int row = min(l0 + r, p.L - 1);
+        const bool row_ok = l0 + r < p.L;
+        h8_t qf[NK];
+        load_q_frags<NK>(p, qf, b, h, row, hh);
+        f16x_t acc[3];
+        scores<NK, REF16>(p, Ks, qf, acc, r, hh, p.scale);
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int s = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                const float a = (row_ok && s < p.S) ? acc[m][i] : 0.f;
+                s1 += a;
+                s2 += a * a;
+            }
+        d1 += (double)s1; d2 += (double)s2;          // fp32 only within one tile (48 values per lane)
+        s1 = 0.f; s2 = 0.f;
+    }
+    d1 = wave_sum_f64(d1);
+    d2 = wave_sum_f64(d2);
+    if (lane == 0) { red[2 * wave] = d1; red[2 * wave + 1] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int w = 0; w < kWaves; ++w) { a1 += red[2 * w]; a2 += red[2 * w + 1]; }
+        const int g = b % p.n_groups;
+        const int idx = ((b / p.n_groups) * p.H + h) * p.nchunks + chunk;
+        double* dst = p.partials + ((long long)g * p.npart + idx) * 2;
+        dst[0] = a1; dst[1] = a2;
+    }
+}
+
+// group std from the partials: every thread of the block gets the same value (fixed summation order)
+__device__ __forceinline__ float group_std(const XattnParams& p, int g, double* red, bool ref16) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* src = p.partials + (long long)g * p.npart * 2;
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = threadIdx.x; i < p.npart; i += kThreads) { a1 += src[2 * i]; a2 += src[2 * i + 1]; }
+    a1 = wave_sum_f64(a1);
+    a2 = wave_sum_f64(a2);
+    if (lane == 0) { red[2 * wave] = a1; red[2 * wave + 1] = a2; }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < kWaves; ++w) { t1 += red[2 * w]; t2 += red[2 * w + 1]; }
+    const double n = (double)(p.Bc / p.n_groups) * p.H * (double)p.L * p.S;
+    double var = (t2 - t1 * t1 / n) / (n - 1.0);             // unbiased, torch.std default
+    var = var > 0.0 ? var : 0.0;
+    float sd = (float)sqrt(var);
+    if (ref16) sd = round_f16(sd);                           // std of an fp16 tensor is a 0-dim fp16 tensor
+    return sd;
+}
+
+// finalises std_out[g] for dsc_region_xattn_std (one block per group)
+template <bool REF16>
+__global__ __launch_bounds__(kThreads) void xattn_std_finalize(XattnParams p) {
+    __shared__ double red[2 * kWaves];
+    const float sd = group_std(p, blockIdx.x, red, REF16);
+    if (threadIdx.x == 0) p.std_out[blockIdx.x] = sd;
+}
+
+// ------------------------------------------------------------------------------------------ phase 2
+template <int NK, bool REF16>
+__global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KP = 16 * NK + 8, DM = (NK + 1) / 2;
+    half_t* Ks = reinterpret_cast<half_t*>(smem);
+    half_t* Vt = Ks + kSMax * KP;
+    double* red = reinterpret_cast<double*>(Vt + 32 * DM * kSP);
+    float* Wt_all = reinterpret_cast<float*>(red + 2 * kWaves);
+    int b, h, chunk;
+    block_to_work(p, b, h, chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const bool has_bias = p.region != nullptr;
+    const bool bias_final = (p.flags & DSC_FLAG_BIAS_IS_FINAL) != 0;
+    const int wt_stride = (32 * p.S + 3) & ~3;
+    float* Wt = Wt_all + wave * wt_stride;
+
+    stage_k<NK>(p, Ks, b, h);
+    stage_vt<DM>(p, Vt, b, h);
+    float sig = 1.f, sd = 1.f;
+    if (has_bias && !bias_final) {
+        sd = group_std(p, b % p.n_groups, red, REF16);       // contains a __syncthreads()
+        sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
+    }
+    const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;   // repeat_interleave, :96-99
+    const int mt = (p.S + 31) >> 5, nt = (p.S + 15) >> 4;
+
+    for (int t = 0; t < p.tiles_per_wave; ++t) {
+        const int l0 = (chunk * kWaves * p.tiles_per_wave + t * kWaves + wave) * 32;
+        const bool tile_ok = l0 < p.L;                       // wave-uniform
+        const int nrows = tile_ok ? min(32, p.L - l0) : 0;
+        const int row = tile_ok ? min(l0 + r, p.L - 1) : 0;
+        h8_t qf[NK];
+        if (tile_ok) {
+            load_q_frags<NK>(p, qf, b, h, row, hh);
+            if (has_bias) {                                  // fp32 region rows l0 .. l0+nrows-1: contiguous
+                const float* src = p.region + ((long long)bw * p.L + l0) * p.S;
+                const int cnt = nrows * p.S;
+                if (((((long long)bw * p.L + l0) * p.S) & 3) == 0 && (cnt & 3) == 0) {
+                    for (int i = lane * 4; i < cnt; i += 256)
+                        *reinterpret_cast<f4x_t*>(Wt + i) = *reinterpret_cast<const f4x_t*>(src + i);
+                } else {
+                    for (int i = lane; i < cnt; i += 64) Wt[i] = src[i];
+                }
+            }
+        }
+        __syncthreads();          // t == 0: K / V^T images complete; every t: this wave's Wt tile is written
+        if (tile_ok) {
+            f16x_t acc[3];
+            scores<NK, REF16>(p, Ks, qf, acc, r, hh, p.scale);
+            const float* wrow = Wt + min(r, nrows - 1) * p.S;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int s = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    float a = acc[m][i];
+                    if (m < mt && s < p.S) {
+                        if (has_bias) {
+                            const float bias = (wrow[s] * sig) * sd;        // w * sigma * std, fp32 (app.py:1004)
+                            a = a + bias;                                   // attention_modify.py:97
+                            if (REF16) a = round_f16(a);
+                        }
+                    } else {
+                        a = -INFINITY;
+                    }
+                    acc[m][i] = a;
+                    mx = fmaxf(mx, a);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __expf(acc[m][i] - mx);
+                    acc[m][i] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.f / sum;
+            h8_t pf[6];                                      // softmax output is an fp16 tensor (:101)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)(acc[m][i] * inv);
+
+            half_t* ob = p.out + b * p.osb + h * p.osh + (long long)row * p.osl;
+            const bool row_ok = l0 + r < p.L;
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm) {
+                if (32 * dm < p.d) {
+                    f16x_t o;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+                    const half_t* vrow = Vt + (32 * dm + r) * kSP + 4 * hh;
+#pragma unroll
+                    for (int tt = 0; tt < 6; ++tt) {
+                        if (tt < nt) {
+                            const h4_t lo = *reinterpret_cast<const h4_t*>(vrow + 16 * tt);
+                            const h4_t hi = *reinterpret_cast<const h4_t*>(vrow + 16 * tt + 8);
+                            const h8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                            o = mfma_32x32x16(vf, pf[tt], o);
+                        }
+                    }
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                        if (row_ok && dd0 < p.d) {
+                            const h4_t ov = {(half_t)o[4 * g4], (half_t)o[4 * g4 + 1], (half_t)o[4 * g4 + 2],
+                                             (half_t)o[4 * g4 + 3]};
+                            *reinterpret_cast<h4_t*>(ob + dd0) = ov;
+                        }
+                    }
+                }
+            }
+        }
+        if (t + 1 < p.tiles_per_wave) __syncthreads();       // Wt is rewritten by the next tile
+    }
+}
+
+template <int NK>
+size_t fwd_lds_bytes(int S) {
+    constexpr int KP = 16 * NK + 8, DM = (NK + 1) / 2;
+    const int wt_stride = (32 * S + 3) & ~3;
+    return (size_t)kSMax * KP * 2 + (size_t)32 * DM * kSP * 2 + 2 * kWaves * 8 + (size_t)kWaves * wt_stride * 4;
+}
+template <int NK>
+size_t stats_lds_bytes() {
+    constexpr int KP = 16 * NK + 8;
+    return (size_t)kSMax * KP * 2 + 2 * kWaves * 8;
+}
+
+int pick_nk(int d) {
+    static const int opts[] = {2, 3, 4, 5, 6, 8, 10};
+    for (int nk : opts) if (16 * nk >= d) return nk;
+    return 0;
+}
+
+void plan(XattnParams& p) {
+    // one wave = one 32-row tile; a workgroup = 4 waves x tiles_per_wave tiles of one (b, h)
+    const int tiles = (p.L + 31) / 32;
+    int tpw = 1;
+    while (tpw < 4 && (long long)p.Bc * p.H * ((tiles + 4 * tpw - 1) / (4 * tpw)) > 2048) tpw *= 2;
+    p.tiles_per_wave = tpw;
+    p.nchunks = (tiles + 4 * tpw - 1) / (4 * tpw);
+    p.npart = (p.Bc / p.n_groups) * p.H * p.nchunks;
+    p.xcd_map = ((p.Bc * p.nchunks) % 8 == 0) ? 1 : 0;
+}
+
+template <int NK, bool REF16>
+int launch_stats(const XattnParams& p, hipStream_t st) {
+    const dim3 grid(p.Bc * p.H * p.nchunks), block(kThreads);
+    hipLaunchKernelGGL((xattn_stats<NK, REF16>), grid, block, stats_lds_bytes<NK>(), st, p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}
+template <int NK, bool REF16>
+int launch_fwd(const XattnParams& p, hipStream_t st) {
+    const size_t lds = fwd_lds_bytes<NK>(p.S);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_fwd<NK, REF16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const dim3 grid(p.Bc * p.H * p.nchunks), block(kThreads);
+    hipLaunchKernelGGL((xattn_fwd<NK, REF16>), grid, block, lds, st, p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}
+
+#define DSC_DISPATCH_NK(nk, FN, ...)                                   \
+    switch (nk) {                                                      \
+        case 2: return FN<2, __VA_ARGS__;                              \
+        case 3: return FN<3, __VA_ARGS__;                              \
+        case 4: return FN<4, __VA_ARGS__;                              \
+        case 5: return FN<5, __VA_ARGS__;                              \
+        case 6: return FN<6, __VA_ARGS__;                              \
+        case 8: return FN<8, __VA_ARGS__;                              \
+        case 10: return FN<10, __VA_ARGS__;                            \
+        default: return DSC_ERR_UNSUPPORTED;                           \
+    }
+
+int dispatch_stats(int nk, bool ref16, const XattnParams& p, hipStream_t st) {
+    if (ref16) { DSC_DISPATCH_NK(nk, launch_stats, true>(p, st)) }
+    DSC_DISPATCH_NK(nk, launch_stats, false>(p, st))
+}
+int dispatch_fwd(int nk, bool ref16, const XattnParams& p, hipStream_t st) {
+    if (ref16) { DSC_DISPATCH_NK(nk, launch_fwd, true>(p, st)) }
+    DSC_DISPATCH_NK(nk, launch_fwd, false>(p, st))
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool strides_ok(const int64_t s[3]) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0; }
+
+int check_common(const void* q, const void* k, int Bc, int H, int L, int S, int d, int n_groups,
+                 const int64_t* qs, const int64_t* ks, int dtype) {
+    if (!q || !k || !qs || !ks) return DSC_ERR_BAD_ARG;
+    if (Bc <= 0 || H <= 0 || L <= 0 || S <= 0 || d <= 0 || n_groups <= 0 || Bc % n_groups != 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
+    if (d % 8 != 0 || d > 160 || S > kSMax) return DSC_ERR_UNSUPPORTED;
+    if (!aligned16(q) || !aligned16(k) || !strides_ok(qs) || !strides_ok(ks)) return DSC_ERR_UNSUPPORTED;
+    return DSC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dsc_region_xattn_workspace_bytes(int Bc, int H, int L, int S, int d, int n_std_groups) {
+    (void)S; (void)d;
+    if (Bc <= 0 || H <= 0 || L <= 0 || n_std_groups <= 0) return 0;
+    XattnParams p{};
+    p.Bc = Bc; p.H = H; p.L = L; p.n_groups = n_std_groups;
+    plan(p);
+    return (size_t)n_std_groups * p.npart * 2 * sizeof(double);
+}
+
+extern "C" int dsc_region_xattn_fwd(const void* q, const void* k, const void* v, void* out, const float* region,
+                                    int Bc, int H, int L, int S, int d, int Bw, int n_std_groups,
+                                    const int64_t q_strides[3], const int64_t k_strides[3],
+                                    const int64_t v_strides[3], const int64_t o_strides[3],
+                                    float sigma_host, const float* sigma_dev, float scale, int dtype, unsigned flags,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common(q, k, Bc, H, L, S, d, n_std_groups, q_strides, k_strides, dtype);
+    if (rc != DSC_OK) return rc;
+    if (!v || !out || !v_strides || !o_strides) return DSC_ERR_BAD_ARG;
+    if (!aligned16(v) || !strides_ok(v_strides) || (reinterpret_cast<uintptr_t>(out) & 7) || !strides_ok(o_strides))
+        return DSC_ERR_UNSUPPORTED;
+    const bool need_stats = region != nullptr && !(flags & DSC_FLAG_BIAS_IS_FINAL);
+    if (region) {
+        if (Bw <= 0 || (Bc * H) % Bw != 0) return DSC_ERR_BAD_ARG;
+        if (reinterpret_cast<uintptr_t>(region) & 3) return DSC_ERR_UNSUPPORTED;
+    }
+    XattnParams p{};
+    p.q = static_cast<const half_t*>(q); p.k = static_cast<const half_t*>(k);
+    p.v = static_cast<const half_t*>(v); p.out = static_cast<half_t*>(out);
+    p.region = region; p.sigma_dev = sigma_dev; p.sigma_host = sigma_host;
+    p.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)d);
+    p.Bc = Bc; p.H = H; p.L = L; p.S = S; p.d = d; p.Bw = region ? Bw : 1; p.n_groups = n_std_groups;
+    p.qsb = q_strides[0]; p.qsl = q_strides[1]; p.qsh = q_strides[2];
+    p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
+    p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
+    p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
+    p.flags = flags;
+    plan(p);
+    if (need_stats) {
+        const size_t need = (size_t)n_std_groups * p.npart * 2 * sizeof(double);
+        if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;
+        p.partials = static_cast<double*>(workspace);
+    }
+    const int nk = pick_nk(d);
+    const bool ref16 = (flags & DSC_FLAG_REF_FP16_ROUNDING) != 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (need_stats) {
+        rc = dispatch_stats(nk, ref16, p, st);
+        if (rc != DSC_OK) return rc;
+    }
+    return dispatch_fwd(nk, ref16, p, st);
+}
+
+extern "C" int dsc_region_xattn_std(const void* q, const void* k, int Bc, int H, int L, int S, int d, int n_std_groups,
+                                    const int64_t q_strides[3], const int64_t k_strides[3], float scale, int dtype,
+                                    unsigned flags, float* std_out, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    int rc = check_common(q, k, Bc, H, L, S, d, n_std_groups, q_strides, k_strides, dtype);
+    if (rc != DSC_OK) return rc;
+    if (!std_out) return DSC_ERR_BAD_ARG;
+    XattnParams p{};
+    p.q = static_cast<const half_t*>(q); p.k = static_cast<const half_t*>(k);
+    p.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)d);
+    p.Bc = Bc; p.H = H; p.L = L; p.S = S; p.d = d; p.Bw = 1; p.n_groups = n_std_groups;
+    p.qsb = q_strides[0]; p.qsl = q_strides[1]; p.qsh = q_strides[2];
+    p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
+    p.flags = flags; p.std_out = std_out;
+    plan(p);
+    const size_t need = (size_t)n_std_groups * p.npart * 2 * sizeof(double);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;
+    p.partials = static_cast<double*>(workspace);
+    const int nk = pick_nk(d);
+    const bool ref16 = (flags & DSC_FLAG_REF_FP16_ROUNDING) != 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = dispatch_stats(nk, ref16, p, st);
+    if (rc != DSC_OK) return rc;
+    if (ref16) hipLaunchKernelGGL(xattn_std_finalize<true>, dim3(n_std_groups), dim3(kThreads), 0, st, p);
+    else hipLaunchKernelGGL(xattn_std_finalize<false>, dim3(n_std_groups), dim3(kThreads), 0, st, p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}

@@ -1,0 +1,97 @@
+/*
+ * dsc_hip.h - C ABI of libdsc_hip.so: the MI355X (gfx950) hot path of the spatially-controlled denoising
+ * step of duongve13112002/DiffusionSpatialControl.
+ *
+ * Conventions (last row):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says host;
+ *   - the caller owns every buffer, including the workspace; nothing is allocated or freed inside;
+ *   - every entry is asynchronous on the `stream` it is given (a hipStream_t passed as void*), re-entrant for
+ *     distinct streams/workspaces, and safe to capture into a hipGraph (no sync, no malloc, no memcpy);
+ *   - the return value is a status: DSC_OK (0) or a negative DSC_ERR_* code; no exception crosses the ABI;
+ *   - strides are in ELEMENTS; the innermost (head-dim / channel) stride is always 1.
+ *
+ * Each entry replaces torch-op sequences issued by the reference's Python; the reference has no FFI of its
+ * own (it is pure Python), so the "interface each one replaces" is the Python function cited beside it.
+ * Paths below are relative to /root/reference/source/.
+ */
+#ifndef DSC_HIP_H
+#define DSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSC_OK                0
+#define DSC_ERR_BAD_ARG      -1   /* null pointer, non-positive size, Bw does not divide Bc*H, ...        */
+#define DSC_ERR_UNSUPPORTED  -2   /* head dim / dtype / alignment outside what the kernels are built for */
+#define DSC_ERR_WORKSPACE    -3   /* workspace missing or smaller than the *_workspace_bytes() answer    */
+#define DSC_ERR_LAUNCH       -4   /* hipLaunchKernel returned an error (hipGetLastError is left set)     */
+
+/* dtype tags */
+#define DSC_F16 0
+/* flags for dsc_region_xattn_fwd */
+#define DSC_FLAG_REF_FP16_ROUNDING 1u  /* round where the reference's fp16 tensors round: scores
+                                          (attention_modify.py:90), std (0-dim fp16), the in-place bias add (:97)
+                                          and the softmax output (:101) */
+#define DSC_FLAG_BIAS_IS_FINAL     2u  /* `region` already holds the additive bias (a custom weight_func was
+                                          evaluated by the caller): add it as is, skip the statistics pass */
+
+/* ABI version of this header; bumped on any signature change. */
+int dsc_abi_version(void);
+/* Static string naming the code-object target the library was built for ("gfx950"). */
+const char* dsc_target_arch(void);
+/* Human-readable text for a status code. */
+const char* dsc_status_string(int status);
+
+/*
+ * Region-biased cross-attention forward - replaces modules/attention_modify.py:74-103
+ * `scaled_dot_product_attention_regionstate` with weight_func = `w * sigma * qk.std()` (app.py:1004), i.e.
+ * rows 2-10 of SURVEY.md 2b, and (with region == NULL) the plain cross-attention SDPA call at :483-485.
+ *
+ *   out[b,l,h,:] = softmax_s( scale*q[b,l,h,:].k[b,s,h,:] + region[bw(b,h),l,s] * sigma * std_g ) . v[b,s,h,:]
+ *
+ *   q, out : Bc x L x H x d   addressed as base + b*sb + l*sl + h*sh + i   (q_strides / o_strides = {sb, sl, sh})
+ *   k, v   : Bc x S x H x d   addressed as base + b*sb + s*ss + h*sh + i   (k_strides / v_strides = {sb, ss, sh})
+ *            so both the processor's [Bc, L, H*d] projection outputs (sl = H*d, sh = d) and a transposed
+ *            [Bc, H, L, d] tensor (sh = L*d, sl = d) are consumed in place, and `out` is written directly in the
+ *            [Bc, L, H*d] layout `to_out[0]` reads (attention_modify.py:487).
+ *   region : fp32 dense [Bw, L, S], Bw divides Bc*H; flattened score row bh = b*H + h takes table row
+ *            bh / (Bc*H/Bw)  (torch.repeat_interleave at :96-99).  NULL = no bias (std pass skipped).
+ *   std_g  : unbiased (N-1) standard deviation of scale*q.k^T over std group g = b % n_std_groups, all heads,
+ *            all L x S scores of the group's rows (:93-95: ONE global std when n_std_groups == 1).
+ *   sigma  : `sigma_dev` (device fp32 scalar) if non-NULL, else `sigma_host`.  A device scalar lets a captured
+ *            graph be replayed for every step without a host sync (the reference syncs, model_k_diffusion.py:1115).
+ *   scale  : <= 0 means 1/sqrt(d)  (attention_modify.py:77; attn.scale is ignored there).
+ *
+ * Requirements: dtype DSC_F16; d % 8 == 0 and d <= 160; S <= 96; all strides % 8 == 0; pointers 16-byte aligned.
+ * Workspace: dsc_region_xattn_workspace_bytes(); contents need no initialisation and carry nothing across calls.
+ */
+size_t dsc_region_xattn_workspace_bytes(int Bc, int H, int L, int S, int d, int n_std_groups);
+
+int dsc_region_xattn_fwd(const void* q, const void* k, const void* v, void* out,
+                         const float* region,
+                         int Bc, int H, int L, int S, int d, int Bw, int n_std_groups,
+                         const int64_t q_strides[3], const int64_t k_strides[3],
+                         const int64_t v_strides[3], const int64_t o_strides[3],
+                         float sigma_host, const float* sigma_dev, float scale,
+                         int dtype, unsigned flags,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Statistics only: writes std_out[g] (fp32, n_std_groups values) = the std the call above would use.
+ * Exposes `qk.std()` of app.py:1004 so that a caller-supplied weight_func that is not the default one can be
+ * evaluated on the host side without materialising the scores more than once.
+ */
+int dsc_region_xattn_std(const void* q, const void* k,
+                         int Bc, int H, int L, int S, int d, int n_std_groups,
+                         const int64_t q_strides[3], const int64_t k_strides[3], float scale,
+                         int dtype, unsigned flags, float* std_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSC_HIP_H */

@@ -1,0 +1,74 @@
+"""CPU-side checks of the C-ABI boundary: the library builds, loads, exports every declared symbol, and
+validates its arguments before touching the GPU."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import diffusionspatialcontrol_amd as dsc
+from diffusionspatialcontrol_amd import _lib, build as dsc_build
+
+
+@pytest.fixture(scope="module")
+def lib():
+    dsc_build.build(verbose=False)
+    return dsc.load_library()
+
+
+def test_exports_every_declared_symbol(lib):
+    names = _lib.declared_symbols()
+    assert "dsc_region_xattn_fwd" in names and len(names) >= 6
+    nm = subprocess.run(["nm", "-D", "--defined-only", dsc.lib_path()], capture_output=True, text=True).stdout
+    for n in names:
+        assert hasattr(lib, n), n
+        assert f" T {n}" in nm, n
+    assert set(_lib._SIGNATURES) == set(names), "every declared entry point needs a ctypes signature"
+
+
+def test_version_and_target(lib):
+    assert lib.dsc_abi_version() == 1
+    assert lib.dsc_target_arch() == b"gfx950"
+    assert lib.dsc_status_string(0) == b"ok"
+    assert b"workspace" in lib.dsc_status_string(-3)
+
+
+def test_code_object_is_gfx950_only():
+    """No multi-arch fat binary, no compatibility targets: the bundle holds gfx950 code objects only."""
+    import re
+    blob = open(dsc.lib_path(), "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    s3 = (ctypes.c_int64 * 3)(8 * 64 * 40, 320, 40)
+    dummy = ctypes.c_void_p(0x1000)
+    call = lambda **kw: lib.dsc_region_xattn_fwd(  # noqa: E731
+        kw.get("q", dummy), dummy, dummy, dummy, kw.get("region", None), kw.get("Bc", 2), 8, 64, kw.get("S", 77),
+        kw.get("d", 40), kw.get("Bw", 2), kw.get("ng", 1), s3, s3, s3, s3, 1.0, None, 0.0, kw.get("dtype", 0), 0,
+        kw.get("ws", None), 0, None)
+    assert call(q=None) == -1                      # null pointer
+    assert call(Bc=0) == -1
+    assert call(ng=3) == -1                        # groups must divide Bc
+    assert call(d=44) == -2                        # head dim not a multiple of 8
+    assert call(d=168) == -2
+    assert call(S=97) == -2
+    assert call(dtype=7) == -2
+    assert call(q=ctypes.c_void_p(0x1004)) == -2   # misaligned
+    assert call(region=dummy, Bw=3) == -1          # Bw must divide Bc*H
+    assert call(region=dummy, ws=None) == -3       # statistics pass needs the workspace
+    assert lib.dsc_region_xattn_workspace_bytes(2, 8, 4096, 77, 40, 1) >= 2 * 8 * 8 * 16
+    assert lib.dsc_region_xattn_workspace_bytes(0, 8, 4096, 77, 40, 1) == 0
+
+
+def test_ops_fail_loudly_without_gpu_or_library(monkeypatch):
+    import torch
+    from diffusionspatialcontrol_amd import ops
+    q = torch.zeros(1, 1, 32, 8, dtype=torch.float16)
+    with pytest.raises(dsc.DscLibraryError):
+        ops.region_xattn(q, q, q)                  # CPU tensors: no fallback
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "lib_path", lambda: os.path.join("/nonexistent", "libdsc_hip.so"))
+    with pytest.raises(dsc.DscLibraryError):
+        _lib.load_library()
