@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py - images/s of the spatially-controlled SD1.5 denoising path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A bench "step" is one pass of the hot path over one batch: ONE full generation (25 DPM++ 2M Karras denoising steps,
+CFG 7.5, every cross-attention carrying the region bias) of `--images-per-gpu` 512x512 latents per GPU.  Workload =
+BASELINE.json configs[1] ("SD1.5 512x512, 25-step DPM++2M Karras, 2 region masks, batch=1, 1xMI355X"); with N GPUs
+every rank generates its own images (weak scaling, no data-path collective: one broadcast of the text embeddings
+and region table before the timed region).  Synthetic data: random-init SD1.5-architecture UNet (seed 0) in fp16,
+seeded text embeddings, rectangular 64-px-aligned region masks.  Inputs are resident in HBM when
+the timed region starts; the final latents stay on the device (VAE decode is outside the path).
+
+Extra objects on the JSON line:
+  roofline     - the region cross-attention forward kernel (`xattn_fwd`, L=4096 level of the same workload) timed
+                 live with HIP events on its own stream: algorithmic bytes per launch / average launch duration vs the
+                 8 TB/s HBM peak.  Algorithmic bytes per launch = 6.60 MB per UNet row (BASELINE.md section 3:
+                 2*(2*L*C + 2*S*C) + 4*L*S at L=4096, C=320, S=77) x Bc rows.
+  cpu_baseline - the oracle (oracle/unet_ref.py, torch fp32, op-for-op unfused like the reference) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed generations (each = 25 denoising steps)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images-per-gpu", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--denoise-steps", type=int, default=25)
+    ap.add_argument("--regions", type=int, default=2)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def synthetic_inputs(size, regions, S=77, ctx=768):
+    """text embeddings (seed 7), token ids, region masks: phrase r occupies columns 2+2r, 3+2r."""
+    from inputs import FakeTokenizer
+    g = torch.Generator().manual_seed(7)
+    emb = torch.randn(2, S, ctx, generator=g)
+    tok = FakeTokenizer()
+    words = [f"object{r}a object{r}b" for r in range(regions)]
+    ids = [49406, 320]
+    for w in words:
+        ids += tok(w).input_ids
+    ids = ids + [49407] * (S - len(ids))
+    import numpy as np
+    pos = np.array([ids], dtype=np.int64)
+    cells = size // 64
+    state = {}
+    for r, w in enumerate(words):
+        m = np.full((size, size), 255, dtype=np.uint8)
+        x0 = (r * cells) // regions
+        x1 = ((r + 1) * cells) // regions
+        m[(cells // 4) * 64:(3 * cells // 4) * 64, x0 * 64:x1 * 64] = 0
+        state[w] = {"map": m, "weight": 0.5, "mask_outsides": 0.0}       # UI defaults app.py:1332-1336
+    return emb, [pos.copy(), pos], state, tok
+
+
+def hip_event_time_ms(fn, iters, stream):
+    """average duration of fn() launched `iters` times on `stream`, measured with HIP events on that stream"""
+    with torch.cuda.stream(stream):
+        for _ in range(5):
+            fn()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(stream)
+        for _ in range(iters):
+            fn()
+        end.record(stream)
+    end.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def roofline_region_xattn(dev, n_img):
+    """the region cross-attention forward kernel at the L=4096 level (C=320, H=8, d=40, S=77), Bc = 2*n_img rows"""
+    from diffusionspatialcontrol_amd import ops
+    Bc, H, L, S, d = 2 * n_img, 8, 4096, 77, 40
+    C = H * d
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(Bc, L, C, generator=g).half().to(dev)
+    k = torch.randn(Bc, S, C, generator=g).half().to(dev)
+    v = torch.randn(Bc, S, C, generator=g).half().to(dev)
+    w = torch.zeros(2, L, S)
+    w[:, 1000:2000, 2:4] = 0.5
+    w = w.to(dev)
+    sig = torch.tensor([7.0], device=dev)
+    out = torch.empty(Bc, L, H, d, dtype=torch.half, device=dev)
+    q4, k4, v4 = q.view(Bc, L, H, d), k.view(Bc, S, H, d), v.view(Bc, S, H, d)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        ops.region_xattn(q4, k4, v4, w, sig, layout="blhd", n_std_groups=n_img, out=out)   # fills the partials
+    st.synchronize()
+    pair = hip_event_time_ms(lambda: ops.region_xattn(q4, k4, v4, w, sig, layout="blhd", n_std_groups=n_img, out=out),
+                             200, st)
+    fwd = hip_event_time_ms(lambda: ops.region_xattn(q4, k4, v4, w, sig, layout="blhd", n_std_groups=n_img, out=out,
+                                                     reuse_stats=True), 200, st)
+    alg_bytes = Bc * (2 * (2 * L * C + 2 * S * C) + 4 * L * S)
+    achieved = alg_bytes / (fwd * 1e-3) / 1e9
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pj):
+        try:
+            traffic = json.load(open(pj)).get("xattn_fwd_hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    return {"kernel": "xattn_fwd<3,true> (region cross-attention forward, L=4096 C=320 S=77, Bc=%d)" % Bc,
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd * 1e3, 2),
+            "stats_plus_fwd_us": round(pair * 1e3, 2)}
+
+
+def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sample_steps, total_steps):
+    """oracle on the host cores: `sample_steps` of the `total_steps` denoising steps of the same image, extrapolated"""
+    from oracle import unet_ref
+    torch.set_num_threads(os.cpu_count())
+    sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    sig = sigmas.float().cpu().tolist()
+    lat = latents.float().cpu() * math.sqrt(sig[0] ** 2 + 1)
+    t0 = time.perf_counter()
+    unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), region_state, guidance, steps_limit=sample_steps)
+    dt = time.perf_counter() - t0
+    per_image = dt / sample_steps * total_steps
+    return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{sample_steps} of {total_steps} denoising steps of one 512x512 image through the fp32 torch oracle "
+                      f"({dt:.1f} s), scaled x{total_steps}/{sample_steps}",
+            "seconds_per_image_extrapolated": round(per_image, 1)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        td.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+
+    from diffusionspatialcontrol_amd import ops
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
+    from diffusionspatialcontrol_amd.parallel import broadcast_generation_inputs, shard_image_indices
+    ops.GRAPHS_ENABLED = not a.no_graph
+
+    cfg = UNetConfig.sd15()
+    torch.manual_seed(0)
+    with torch.device(dev):
+        unet = UNet2DConditionModel(cfg)
+    unet = unet.half().eval()
+    emb, ids, state, tok = synthetic_inputs(a.size, a.regions)
+    emb = emb.to(dev)
+    if dist:                                                    # rank 0's embeddings are THE embeddings
+        emb = broadcast_generation_inputs(emb, src=0)
+    pipe = StableDiffusionPipeline(None, None, tok, unet, SD15Scheduler())
+    n_img = a.images_per_gpu
+    my_images = shard_image_indices(n_img * world, rank, world)
+    lat = torch.stack([torch.randn(4, a.size // 8, a.size // 8, generator=torch.Generator().manual_seed(1000 + i))
+                       for i in my_images]).half().to(dev)
+
+    def generate():
+        return pipe.txt2img(None, height=a.size, width=a.size, num_inference_steps=a.denoise_steps, guidance_scale=7.5,
+                            latents=lat, output_type="latent", region_map_state=state, sampler_name="sample_dpmpp_2m",
+                            sampler_opt={"scheduler": "karras"}, prompt_embeds=emb[1:2], negative_prompt_embeds=emb[0:1],
+                            text_input_ids=ids, num_images_per_prompt=n_img)[0]
+
+    out = None
+    for _ in range(a.warmup):
+        out = generate()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = generate()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        dt = tt.item()
+    finite = bool(torch.isfinite(out).all().item())
+
+    if rank == 0:
+        images = n_img * world * a.steps
+        res = {
+            "metric": "512x512 images/sec, SD1.5 25-step DPM++2M Karras with region-biased cross-attention",
+            "value": round(images / dt, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SD1.5 {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
+                                   f"{a.regions} region masks, {n_img} image(s) per GPU per generation",
+                       "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
+                       "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite},
+        }
+        res["roofline"] = roofline_region_xattn(dev, n_img)
+        if world == 1 and not a.no_cpu_baseline:
+            from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
+            rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)
+            sig = pipe.get_sigmas(a.denoise_steps, {"scheduler": "karras"}).half()
+            text = torch.cat([emb[0:1], emb[1:2]]).half()
+            res["cpu_baseline"] = cpu_baseline(unet, cfg, sig, text, rs, lat[:1], 7.5, a.cpu_sample_steps, a.denoise_steps)
+        print(json.dumps(res), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -458,7 +458,7 @@ extern "C" int dsc_region_xattn_fwd(const void* q, const void* k, const void* v,
     const int nk = pick_nk(d);
     const bool ref16 = (flags & DSC_FLAG_REF_FP16_ROUNDING) != 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (need_stats) {
+    if (need_stats && !(flags & DSC_FLAG_REUSE_STATS)) {
         rc = dispatch_stats(nk, ref16, p, st);
         if (rc != DSC_OK) return rc;
     }

@@ -1,0 +1,219 @@
+"""Attention processors for the MI355X hot path - drop-in counterparts of reference
+`source/modules/attention_modify.py`:
+
+  * `scaled_dot_product_attention_regionstate` (:74-103)  -> one fused HIP call (two launches)
+  * `AttnProcessor2_0` (:405-503) - the live processor (app.py:479-481)
+  * `AttnProcessor` (:106-207)    - same arithmetic through `get_attention_scores` (:39-70); verified
+                                    bit-equal to AttnProcessor2_0 in fp32, so both classes share one
+                                    implementation here and differ only in which `scale` they honour
+Same call signature, same `region_prompt` contract:
+    {"region_state": {L: FloatTensor[Bw, L, S]} | non-dict, "sigma": 0-dim tensor, "weight_func": callable}
+
+What changes underneath:
+  * the scores are never materialised: q.k^T, *scale, std(), w*sigma*std, repeat_interleave, +=, softmax, @v run
+    inside libdsc_hip.so (diffusionspatialcontrol_amd/csrc/region_xattn.hip);
+  * the region table is uploaded ONCE per table object instead of once per call (:481 `.to(query.device)`);
+  * `weight_func` is a caller-supplied callable (app.py:1004 builds a fresh lambda per request): it is probed once
+    with two tiny tensors; if it behaves as `w * sigma * qk.std()` the fused path runs, otherwise the scores are
+    materialised, the callable is evaluated as the reference would, and its result is added by the same kernel.
+There is no CPU path: tensors must live on the GPU and libdsc_hip.so must be built.
+"""
+import math
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+USE_PEFT_BACKEND = True
+
+
+# ----------------------------------------------------------------------------- weight_func dispatch
+_PROBES = (
+    (torch.tensor([[[0.25, -1.5, 3.0], [0.0, 2.0, -0.5]]]), torch.tensor(1.75),
+     torch.tensor([[[0.5, -2.0, 4.0], [1.0, 0.0, -3.0]]])),
+    (torch.tensor([[[-0.75, 0.125, 1.0], [4.0, -2.5, 0.0]]]), torch.tensor(0.3125),
+     torch.tensor([[[7.0, 1.0, -1.0], [2.5, -4.0, 0.25]]])),
+)
+_WF_CACHE = OrderedDict()
+
+
+def weight_func_is_default(weight_func):
+    """True iff `weight_func(w, sigma, qk)` equals `w * sigma * qk.std()` on two probes."""
+    key = id(weight_func)
+    hit = _WF_CACHE.get(key)
+    if hit is not None and hit[0] is weight_func:
+        return hit[1]
+    ok = True
+    try:
+        for w, s, qk in _PROBES:
+            r = weight_func(w, s, qk)
+            e = w * s * qk.std()
+            if not (torch.is_tensor(r) and r.shape == e.shape and torch.allclose(r.float(), e, rtol=1e-6, atol=0.0)):
+                ok = False
+                break
+    except Exception:  # noqa: BLE001 - any failure on the probe means "not the default": take the generic path
+        ok = False
+    _WF_CACHE[key] = (weight_func, ok)          # keeps the callable alive so its id cannot be reused
+    while len(_WF_CACHE) > 32:
+        _WF_CACHE.popitem(last=False)
+    return ok
+
+
+# ----------------------------------------------------------------------------- region table residency
+_TABLE_CACHE = OrderedDict()
+
+
+def resident_table(w, device):
+    """fp32 device copy of a region table, made once per (tensor object, version, device)."""
+    if w.device == device and w.dtype == torch.float32 and w.is_contiguous():
+        return w
+    key = (id(w), w._version, str(device))
+    hit = _TABLE_CACHE.get(key)
+    if hit is not None and hit[0] is w:
+        _TABLE_CACHE.move_to_end(key)
+        return hit[1]
+    dw = w.to(device=device, dtype=torch.float32).contiguous()
+    _TABLE_CACHE[key] = (w, dw)
+    while len(_TABLE_CACHE) > 64:
+        _TABLE_CACHE.popitem(last=False)
+    return dw
+
+
+_SIGMA_CACHE = OrderedDict()
+
+
+def _sigma_arg(sigma, device):
+    """A python float (host scalar) or an fp32 device scalar (no host sync) for the kernel."""
+    if not torch.is_tensor(sigma):
+        return float(sigma)
+    if not sigma.is_cuda:
+        return float(sigma)
+    if sigma.dtype == torch.float32:
+        return sigma
+    key = (id(sigma), sigma._version)
+    hit = _SIGMA_CACHE.get(key)
+    if hit is not None and hit[0] is sigma:
+        return hit[1]
+    s32 = sigma.detach().float().reshape(1)
+    _SIGMA_CACHE[key] = (sigma, s32)
+    while len(_SIGMA_CACHE) > 8:
+        _SIGMA_CACHE.popitem(last=False)
+    return s32
+
+
+def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None):
+    w_dev = resident_table(w, q.device)
+    ref16 = q.dtype == torch.float16
+    if weight_func is None or weight_func_is_default(weight_func):
+        return ops.region_xattn(q, k, v, w_dev, _sigma_arg(sigma, q.device), layout=layout, n_std_groups=n_std_groups,
+                                scale=scale, ref_fp16_rounding=ref16)
+    # generic weight_func: evaluate it the way the reference does (attention_modify.py:90-95), then let the kernel
+    # add its result (flag BIAS_IS_FINAL).  Slow path by construction - the scores are materialised once.
+    qh, kh = (q, k) if layout == "bhld" else (q.transpose(1, 2), k.transpose(1, 2))
+    sf = scale if scale else 1.0 / math.sqrt(q.shape[-1])
+    scores = (qh @ kh.transpose(-2, -1)) * sf
+    bias = weight_func(w_dev, sigma, scores.reshape(-1, scores.shape[-2], scores.shape[-1]))
+    bias = torch.broadcast_to(bias, w_dev.shape).float().contiguous()
+    return ops.region_xattn(q, k, v, bias, 1.0, layout=layout, scale=scale, bias_is_final=True, ref_fp16_rounding=ref16)
+
+
+def scaled_dot_product_attention_regionstate(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
+                                             scale=None, weight_func=None, region_state=None, sigma=None,
+                                             n_std_groups=1) -> torch.Tensor:
+    """Same signature and result as attention_modify.py:74-103; query [Bc,H,L,d], key/value [Bc,H,S,d]."""
+    if attn_mask is not None or is_causal or dropout_p != 0.0:
+        raise NotImplementedError("attn_mask / is_causal / dropout are not on the hot path (never used by app.py)")
+    return _region_attention(query, key, value, region_state, sigma, weight_func, "bhld", n_std_groups, scale)
+
+
+def get_attention_scores(attn, query, key, attention_mask=None):
+    """attention_modify.py:39-70 (used by the generic weight_func path of callers that want raw scores)."""
+    if attention_mask is not None:
+        raise NotImplementedError("attention masks are not on the hot path")
+    return torch.baddbmm(torch.empty(query.shape[0], query.shape[1], key.shape[1], dtype=query.dtype, device=query.device),
+                         query, key.transpose(-1, -2), beta=0, alpha=attn.scale)
+
+
+class _RegionProcessor:
+    """Shared body of AttnProcessor / AttnProcessor2_0 (reference :106-207 and :414-503)."""
+
+    honours_attn_scale = False
+
+    def __init__(self, n_std_groups: int = 1):
+        # 1 = the reference: ONE std over the whole call (all rows, all heads).  The pipeline sets B when it
+        # micro-batches B images in the row layout [u_0..u_{B-1}, c_0..c_{B-1}] so that each image keeps the std
+        # group the reference's one-image-per-call k-diffusion path gives it.
+        self.n_std_groups = n_std_groups
+
+    def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states=None,
+                 attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, scale: float = 1.0,
+                 region_prompt=None, ip_adapter_masks=None) -> torch.Tensor:
+        residual = hidden_states
+        img_sequence_length = hidden_states.shape[1]              # :427 - dim 1 also for 4-D input
+        if attn.spatial_norm is not None:
+            hidden_states = attn.spatial_norm(hidden_states, temb)
+        input_ndim = hidden_states.ndim
+        if input_ndim == 4:
+            batch_size, channel, height, width = hidden_states.shape
+            hidden_states = hidden_states.view(batch_size, channel, height * width).transpose(1, 2)
+        is_xattn = encoder_hidden_states is not None and region_prompt is not None
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are not on the hot path (app.py never passes one)")
+        if attn.group_norm is not None:
+            hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
+        query = attn.to_q(hidden_states)
+        is_self = encoder_hidden_states is None
+        if is_self:
+            encoder_hidden_states = hidden_states
+        elif attn.norm_cross:
+            encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
+        key = attn.to_k(encoder_hidden_states)
+        value = attn.to_v(encoder_hidden_states)
+        B, L, C = query.shape
+        H = attn.heads
+        d = C // H
+        S = key.shape[1]
+        q4, k4, v4 = query.view(B, L, H, d), key.view(B, S, H, d), value.view(B, S, H, d)
+        sc = attn.scale if self.honours_attn_scale else None
+        if is_xattn and isinstance(region_prompt["region_state"], dict):
+            w = region_prompt["region_state"][img_sequence_length]          # KeyError when L is not a level (:481)
+            groups = region_prompt.get("n_std_groups", self.n_std_groups)
+            out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
+                                    groups, sc)
+        elif not is_self:
+            out = ops.region_xattn(q4, k4, v4, None, layout="blhd", scale=sc, ref_fp16_rounding=False)
+        else:
+            out = ops.self_attention(q4, k4, v4, scale=sc)                  # [B, L, H, d]
+        hidden_states = out.reshape(B, L, C)
+        hidden_states = attn.to_out[0](hidden_states)
+        hidden_states = attn.to_out[1](hidden_states)
+        if input_ndim == 4:
+            hidden_states = hidden_states.transpose(-1, -2).reshape(batch_size, channel, height, width)
+        if attn.residual_connection:
+            hidden_states = hidden_states + residual
+        if attn.rescale_output_factor != 1.0:
+            hidden_states = hidden_states / attn.rescale_output_factor
+        return hidden_states
+
+
+class AttnProcessor2_0(_RegionProcessor):
+    r"""Counterpart of reference `AttnProcessor2_0` (:405-503): scale is 1/sqrt(head_dim) on every branch."""
+    honours_attn_scale = False
+
+
+class AttnProcessor(_RegionProcessor, nn.Module):
+    r"""Counterpart of reference `AttnProcessor` (:106-207): scores use `attn.scale` (:57-63)."""
+    honours_attn_scale = True
+
+    def __init__(self, n_std_groups: int = 1):
+        nn.Module.__init__(self)
+        _RegionProcessor.__init__(self, n_std_groups)
+
+    def forward(self, *a, **k):
+        return _RegionProcessor.__call__(self, *a, **k)
+
+    __call__ = _RegionProcessor.__call__

@@ -1,0 +1,298 @@
+"""k-diffusion text-to-image pipeline for the MI355X hot path - counterpart of reference
+`source/modules/model_k_diffusion.py` (`ModelWrapper` :85-98, `StableDiffusionPipeline` :101-, `setup_unet`
+:138-141, `get_scheduler` :143-146, `get_sigmas` :848-882, `prepare_latents` :428-456, `txt2img` :943-1231).
+
+Scope: the denoising loop of `txt2img`.  Prompt encoding (CLIP + A1111 chunking),
+VAE decode, ControlNet / T2I-Adapter / IP-Adapter and hires-upscale are the "next" rows and raise
+NotImplementedError when requested; embeddings and token ids are passed in (`prompt_embeds`,
+`negative_prompt_embeds`, `text_input_ids`), and `output_type="latent"` returns the final latents.
+
+Two execution modes produce the same numbers:
+  * protocol mode (`fused=False`): the reference's control flow - a `model_fn(x, sigma)` closure that duplicates the
+    latent, attaches `region_prompt`, calls `CompVisDenoiser` -> `ModelWrapper.apply_model` -> UNet, combines CFG
+    (:1091-1171) - handed to `sampler(model_fn, latents, sigmas=...)` (:1175).  Any sampler callable works.
+  * fused mode (`fused=True`, default for `sample_dpmpp_2m`): the UNet forward of one step is captured ONCE into a
+    HIP graph over static buffers (sigma and the timestep are device scalars, so the same graph serves all 25
+    steps); between replays ONE HIP launch (dsc_cfg_dpmpp2m_step) does CFG combine + eps->denoised + the DPM++ 2M
+    update + the next step's `cat([x]*2) * c_in`.  No device->host sync inside the loop (the reference has two
+    per step: `sigma.item()` :1115 and the sampler's `sigmas[i+1] == 0` test).
+Batches of B > 1 images use the reference's row layout [u_0..u_{B-1}, c_0..c_{B-1}] (:1021,1097) with one std group
+per image (`n_std_groups = B`), which is what B separate reference calls compute (the reference itself cannot batch:
+external_k_diffusion.py:109-114 broadcasts c_in[B] against input[2B]).
+"""
+import importlib
+import inspect
+import time
+from typing import List, Optional, Union
+
+import torch
+
+from .. import ops
+from . import sampling
+from .encode_region_map_function import encode_region_map
+from .external_k_diffusion import CompVisDenoiser
+
+
+class ModelWrapper:
+    def __init__(self, model, alphas_cumprod):
+        self.model = model
+        self.alphas_cumprod = alphas_cumprod
+
+    def apply_model(self, *args, **kwargs):
+        if len(args) == 3:
+            encoder_hidden_states = args[-1]
+            args = args[:2]
+        if kwargs.get("cond", None) is not None:
+            encoder_hidden_states = kwargs.pop("cond")
+        return self.model(*args, encoder_hidden_states=encoder_hidden_states, **kwargs).sample
+
+
+class SD15Scheduler:
+    """Stand-in for the diffusers scheduler object the reference pipeline reads `alphas_cumprod` and
+    `config.prediction_type` from (:138-141): scaled_linear betas 0.00085 -> 0.012, 1000 steps (SD1.5)."""
+
+    def __init__(self, beta_start=0.00085, beta_end=0.012, num_train_timesteps=1000, prediction_type="epsilon"):
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.config = type("Cfg", (), {"prediction_type": prediction_type})()
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """reference :71-82 (arXiv 2305.08891 sec. 3.4)"""
+    dims = list(range(1, noise_pred_text.ndim))
+    factor = noise_pred_text.std(dim=dims, keepdim=True) / noise_cfg.std(dim=dims, keepdim=True)
+    return guidance_rescale * (noise_cfg * factor) + (1 - guidance_rescale) * noise_cfg
+
+
+class StableDiffusionPipeline:
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, feature_extractor=None, image_encoder=None):
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet, self.scheduler = unet, scheduler
+        self.feature_extractor, self.image_encoder = feature_extractor, image_encoder
+        self.controlnet = None
+        self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
+        self._do_classifier_free_guidance = True
+        self._graphs = {}
+        self.setup_unet(self.unet)
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def device(self):
+        return self.unet.device
+
+    @property
+    def _execution_device(self):
+        return self.unet.device
+
+    @property
+    def do_classifier_free_guidance(self):
+        return self._do_classifier_free_guidance
+
+    def to(self, device):
+        self.unet.to(device)
+        self.k_diffusion_model.to(device)
+        return self
+
+    def setup_unet(self, unet):
+        self.unet = unet
+        if getattr(self.scheduler.config, "prediction_type", "epsilon") == "v_prediction":
+            raise NotImplementedError("v-prediction models are outside the SD1.5 hot path")
+        self.k_diffusion_model = CompVisDenoiser(ModelWrapper(unet, self.scheduler.alphas_cumprod))
+        self.k_diffusion_model.to(unet.device)
+        self._graphs = {}
+
+    def get_scheduler(self, scheduler_type: str):
+        """reference :143-146 resolves the name in `k_diffusion.sampling`; here in the build's own sampling module"""
+        return getattr(importlib.import_module(sampling.__name__), scheduler_type)
+
+    def get_sigmas(self, steps, params):
+        """reference :848-882 (karras / default branches)"""
+        discard = params.get("discard_next_to_last_sigma", False)
+        steps += 1 if discard else 0
+        if params.get("scheduler", None) == "karras":
+            smin, smax = self.k_diffusion_model.sigmas[0].item(), self.k_diffusion_model.sigmas[-1].item()
+            sigmas = sampling.get_sigmas_karras(n=steps, sigma_min=smin, sigma_max=smax, device=self.device)
+        elif params.get("scheduler", None) in ("exponential", "polyexponential"):
+            raise NotImplementedError("only the karras and default schedules are on the hot path")
+        else:
+            sigmas = self.k_diffusion_model.get_sigmas(steps)
+        if discard:
+            sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
+        return sigmas
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels_latents, height // 8, width // 8)
+        if latents is None:
+            gdev = generator.device if generator is not None else device
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        return latents
+
+    def get_sampler_extra_args_t2i(self, sigmas, eta, steps, sampler_opt, latents, seed, func):
+        params = inspect.signature(func).parameters
+        extra = {}
+        if "eta" in params:
+            extra["eta"] = eta
+        if "sigma_min" in params:
+            extra["sigma_min"], extra["sigma_max"] = sigmas[0].item(), sigmas[-1].item()
+        if "n" in params:
+            extra["n"] = steps
+        else:
+            extra["sigmas"] = sigmas
+        if sampler_opt.get("brownian_noise", False):
+            raise NotImplementedError("SDE samplers are outside the hot path")
+        return extra
+
+    def latent_to_image(self, latents, output_type):
+        if output_type == "latent":
+            return latents
+        if self.vae is None:
+            raise NotImplementedError("VAE decode is the next row after the denoising loop (SURVEY.md 8f rank 1); "
+                                      "pass output_type='latent'")
+        image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
+        return image
+
+    # ------------------------------------------------------------------ txt2img
+    @torch.no_grad()
+    def txt2img(self, prompt: Union[str, List[str], None] = None, height: int = 512, width: int = 512,
+                num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None, eta: float = 0.0,
+                generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
+                output_type: Optional[str] = "pil", callback_steps: Optional[int] = 1, upscale=False,
+                region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
+                latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), seed=0,
+                ip_adapter_image=None, control_img=None, image_t2i_adapter=None, guidance_rescale: float = 0.0,
+                cross_attention_kwargs=None, clip_skip=None, long_encode=0, num_images_per_prompt=1,
+                ip_adapter_image_embeds=None,
+                # build-specific inputs (the prompt encoders are a "next" row):
+                prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                text_input_ids=None, fused: Optional[bool] = None, **unsupported):
+        if upscale or ip_adapter_image is not None or ip_adapter_image_embeds is not None or control_img is not None \
+                or image_t2i_adapter is not None or self.controlnet is not None or latent_processing:
+            raise NotImplementedError("hires upscale / IP-Adapter / ControlNet / T2I-Adapter / latent previews are "
+                                      "outside the denoising hot path built here (SURVEY.md 8f)")
+        if prompt_embeds is None:
+            raise NotImplementedError("prompt encoding (CLIP + A1111 chunking, encoder_prompt_modify.py) is a 'next' "
+                                      "row: pass prompt_embeds / negative_prompt_embeds / text_input_ids")
+        sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
+        device = self._execution_device
+        self._do_classifier_free_guidance = guidance_scale > 1.0
+        cfg = self._do_classifier_free_guidance
+        n_img = prompt_embeds.shape[0] * num_images_per_prompt
+        text = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        if cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("classifier-free guidance needs negative_prompt_embeds")
+            text = torch.cat([negative_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0), text])   # :1021
+        text = text.to(device=device, dtype=self.unet.dtype)
+        # sigmas are cast to the model dtype on the device (:1027-1029): fp16 rounding is part of the schedule
+        sigmas = self.get_sigmas(num_inference_steps, sampler_opt).to(device, dtype=text.dtype)
+        latents = self.prepare_latents(n_img, self.unet.config.in_channels, height, width, text.dtype, device,
+                                       generator, latents)
+        latents = latents * (sigmas[0] ** 2 + 1) ** 0.5                                                      # :1043
+        if text_input_ids is None:
+            text_input_ids = [None, None]
+        region_state = encode_region_map(self, region_map_state, width=width, height=height,
+                                         num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)  # :1050
+        cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
+        if fused is None:
+            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg
+        if fused:
+            latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
+                                          cross_attention_kwargs, start_time, timeout)
+        else:
+            latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
+                                             guidance_rescale, n_img, cross_attention_kwargs, eta,
+                                             num_inference_steps, sampler_opt, seed, start_time, timeout)
+        return [self.latent_to_image(latents, output_type)]
+
+    # ---- protocol mode: the reference's model_fn closure (:1091-1171) + sampler call (:1172-1175)
+    def _denoise_protocol(self, sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
+                          guidance_rescale, n_img, cross_attention_kwargs, eta, steps, sampler_opt, seed, start_time,
+                          timeout):
+        cfg = self.do_classifier_free_guidance
+        kdm = self.k_diffusion_model
+
+        def model_fn(x, sigma):
+            if start_time > 0 and timeout > 0:
+                assert (time.time() - start_time) < timeout, "inference process timed out"
+            latent_model_input = torch.cat([x] * 2) if cfg else x
+            cross_attention_kwargs["region_prompt"] = {
+                "region_state": region_state, "sigma": sigma[0], "weight_func": weight_func, "n_std_groups": n_img}
+            if latent_model_input.dtype != text.dtype:
+                latent_model_input = latent_model_input.to(text.dtype)
+            # CompVisDenoiser.forward broadcasts sigma[B] against 2B rows (external_k_diffusion.py:109-114), which
+            # only works for B == 1 in the reference; repeat sigma per row so that B > 1 works too
+            sig_rows = torch.cat([sigma] * 2) if cfg else sigma
+            noise_pred = kdm(latent_model_input, sig_rows, cond=text, cross_attention_kwargs=cross_attention_kwargs)
+            if cfg:
+                u, c = noise_pred.chunk(2)
+                noise_pred = u + guidance_scale * (c - u)
+                if guidance_rescale > 0.0:
+                    noise_pred = rescale_noise_cfg(noise_pred, c, guidance_rescale=guidance_rescale)
+            return noise_pred
+
+        extra = self.get_sampler_extra_args_t2i(sigmas, eta, steps, sampler_opt, latents, seed, sampler)
+        return sampler(model_fn, latents, **extra)
+
+    # ---- fused mode
+    def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs):
+        """Static buffers + the captured UNet step for this (shape, region tables, text) combination."""
+        st = self._graphs.get(key)
+        if st is not None:
+            st["text"].copy_(text)
+            return st
+        dev, dt = text.device, text.dtype
+        rows = 2 * n_img
+        st = {
+            "x_in": torch.zeros((rows,) + lat_shape[1:], device=dev, dtype=dt),
+            "t": torch.zeros(rows, device=dev, dtype=torch.float32),
+            "sigma": torch.ones(1, device=dev, dtype=torch.float32),
+            "text": text.clone(),
+        }
+        kw = dict(cross_attention_kwargs)
+        kw["region_prompt"] = {"region_state": region_state, "sigma": st["sigma"], "weight_func": weight_func,
+                               "n_std_groups": n_img}
+
+        def step():
+            return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw).sample
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):                   # warm-up: table upload, workspaces, MIOpen/hipBLASLt algo selection
+                st["eps"] = step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        if not ops.GRAPHS_ENABLED:
+            st["run"] = lambda: st.__setitem__("eps", step())
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st["eps"] = step()
+            st["graph"] = g
+            st["run"] = g.replay
+        self._graphs = {key: st}                 # keep one: the tables/text of the previous generation are dead
+        return st
+
+    def _denoise_fused(self, latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
+                       cross_attention_kwargs, start_time, timeout):
+        kdm = self.k_diffusion_model
+        sig = sigmas.detach().float().cpu().tolist()                 # the only device->host transfer, before the loop
+        coeffs = sampling.dpmpp_2m_coefficients(sig)
+        key = (n_img, tuple(latents.shape), id(region_state) if isinstance(region_state, dict) else None,
+               tuple(text.shape), text.dtype)
+        st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs)
+        x = latents.contiguous().clone()
+        old = torch.zeros_like(x)
+        c_in, _, t = kdm.step_scalars(sig[0])
+        ops.prepare_unet_input(x, c_in, t, sig[0], st["x_in"], st["t"], st["sigma"])
+        for i, (a, b, c) in enumerate(coeffs):
+            if start_time > 0 and timeout > 0:
+                assert (time.time() - start_time) < timeout, "inference process timed out"
+            st["run"]()
+            nxt = sig[i + 1]
+            c_in_n, _, t_n = kdm.step_scalars(nxt) if nxt > 0 else (1.0, 0.0, 0.0)
+            # x <- a*x + b*D + c*D_old with D = x - sigma*(eps_u + g*(eps_c - eps_u)); also writes next x_in/t/sigma
+            ops.cfg_dpmpp2m_step(x, st["eps"], old, sig[i], guidance_scale, a, b, c, c_in_n, t_n, max(nxt, 1e-10),
+                                 st["x_in"], st["t"], st["sigma"])
+        return x

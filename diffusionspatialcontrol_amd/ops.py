@@ -8,6 +8,7 @@ from . import _lib
 
 FLAG_REF_FP16_ROUNDING = 1
 FLAG_BIAS_IS_FINAL = 2
+FLAG_REUSE_STATS = 4
 
 _WS = {}
 
@@ -50,7 +51,7 @@ def _blhd_strides(t, layout):
 
 
 def region_xattn(q, k, v, region=None, sigma=1.0, *, layout="bhld", n_std_groups=1, scale=None,
-                 ref_fp16_rounding=True, bias_is_final=False, out=None):
+                 ref_fp16_rounding=True, bias_is_final=False, out=None, reuse_stats=False):
     """softmax(scale*q.k^T + region*sigma*std) . v  on the GPU (dsc_region_xattn_fwd).
 
     layout 'bhld': q [Bc,H,L,d], k/v [Bc,H,S,d] -> out [Bc,H,L,d] (the shape of
@@ -88,7 +89,8 @@ def region_xattn(q, k, v, region=None, sigma=1.0, *, layout="bhld", n_std_groups
             sig_host = float(sigma)
     else:
         sig_host = float(sigma)
-    flags = (FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0) | (FLAG_BIAS_IS_FINAL if bias_is_final else 0)
+    flags = (FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0) | (FLAG_BIAS_IS_FINAL if bias_is_final else 0) \
+        | (FLAG_REUSE_STATS if reuse_stats else 0)
     nbytes = lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups)
     ws = _workspace(q.device, nbytes)
     rc = lib.dsc_region_xattn_fwd(
@@ -117,4 +119,85 @@ def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp1
         FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0, ctypes.c_void_p(out.data_ptr()),
         ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _stream_ptr(q))
     _lib.check(rc, "dsc_region_xattn_std")
+    return out
+
+
+# ----------------------------------------------------------------------------- ops of the UNet step
+# NOTE: entries marked INTERIM run as torch-ROCm library calls until their HIP kernel lands in csrc/.
+def self_attention(q, k, v, scale=None):
+    """softmax(q.k^T * scale) . v for q/k/v [B, L, H, d] views -> [B, L, H, d] contiguous.  INTERIM: torch SDPA."""
+    _require_gpu(q, k, v)
+    o = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
+                                                         scale=scale)
+    return o.transpose(1, 2).contiguous()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def groupnorm_silu(x, groups, weight, bias, eps, act):
+    """GroupNorm(groups, eps) [+ SiLU] over NCHW fp16 [B, C, h, w] (dsc_groupnorm_silu: two HIP launches)."""
+    _require_gpu(x)
+    lib = _lib.load_library()
+    if x.dtype != torch.float16:
+        raise TypeError("groupnorm_silu: fp16 only")
+    x = x.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    ws = _workspace(x.device, lib.dsc_groupnorm_workspace_bytes(B, C, hw, groups))
+    rc = lib.dsc_groupnorm_silu(_p(x), _p(y), _p(weight), _p(bias), B, C, hw, groups, float(eps), 1 if act else 0, 0,
+                                _p(ws), ws.numel() * 8, _stream_ptr(x))
+    _lib.check(rc, "dsc_groupnorm_silu")
+    return y
+
+
+def geglu(x):
+    """hidden * gelu(gate) for x = [..., 2n] fp16 contiguous (dsc_geglu)."""
+    _require_gpu(x)
+    lib = _lib.load_library()
+    x = x.contiguous()
+    n = x.shape[-1] // 2
+    y = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    rc = lib.dsc_geglu(_p(x), _p(y), x.numel() // (2 * n), n, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_geglu")
+    return y
+
+
+# ----------------------------------------------------------------------------- sampler step
+GRAPHS_ENABLED = True      # the fused pipeline captures the UNet step into a HIP graph (torch.cuda.CUDAGraph)
+
+
+def prepare_unet_input(x, c_in, t, sigma, x_in, t_buf, sigma_buf):
+    """x_in = [x; x] * c_in, t_buf[:] = t, sigma_buf[0] = sigma (dsc_prepare_unet_input)."""
+    _require_gpu(x, x_in, t_buf, sigma_buf)
+    n_img = x.shape[0]
+    rc = _lib.load_library().dsc_prepare_unet_input(_p(x), c_in, t, sigma, _p(x_in), _p(t_buf), _p(sigma_buf), n_img,
+                                                    x.numel() // n_img, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_prepare_unet_input")
+
+
+def cfg_dpmpp2m_step(x, eps, old, sigma, guidance, a, b, c, c_in_next, t_next, sigma_next, x_in, t_buf, sigma_buf):
+    """One launch: CFG combine + eps->denoised + DPM++ 2M update (in place on x, old) + next UNet input."""
+    _require_gpu(x, eps, old, x_in)
+    n_img = x.shape[0]
+    rc = _lib.load_library().dsc_cfg_dpmpp2m_step(_p(x), _p(eps), _p(old), sigma, guidance, a, b, c, c_in_next, t_next,
+                                                  sigma_next, _p(x_in), _p(t_buf), _p(sigma_buf), n_img,
+                                                  x.numel() // n_img, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_cfg_dpmpp2m_step")
+
+
+def dpmpp2m_update(x, denoised, old, a, b, c):
+    """a*x + b*denoised + c*old as one launch (dsc_dpmpp2m_update)."""
+    _require_gpu(x, denoised)
+    x, denoised = x.contiguous(), denoised.contiguous()
+    if old is not None:
+        old = old.contiguous()
+    elif c != 0.0:
+        raise ValueError("c != 0 needs the previous denoised estimate")
+    out = torch.empty_like(x)
+    rc = _lib.load_library().dsc_dpmpp2m_update(_p(x), _p(denoised), _p(old), a, b, c if old is not None else 0.0,
+                                                _p(out), x.numel(), 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_dpmpp2m_update")
     return out

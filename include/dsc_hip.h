@@ -36,6 +36,8 @@ extern "C" {
 #define DSC_FLAG_REF_FP16_ROUNDING 1u  /* round where the reference's fp16 tensors round: scores
                                           (attention_modify.py:90), std (0-dim fp16), the in-place bias add (:97)
                                           and the softmax output (:101) */
+#define DSC_FLAG_REUSE_STATS       4u  /* measurement aid: skip the statistics launch and reuse the partial sums the
+                                          previous identical call left in `workspace` (times the forward kernel alone) */
 #define DSC_FLAG_BIAS_IS_FINAL     2u  /* `region` already holds the additive bias (a custom weight_func was
                                           evaluated by the caller): add it as is, skip the statistics pass */
 
@@ -90,6 +92,46 @@ int dsc_region_xattn_std(const void* q, const void* k,
                          const int64_t q_strides[3], const int64_t k_strides[3], float scale,
                          int dtype, unsigned flags, float* std_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Fused sampler step for the k-diffusion DPM++ 2M loop with classifier-free guidance - replaces, per step,
+ * `torch.cat([x]*2)` + `input * c_in` (model_k_diffusion.py:1097, external_k_diffusion.py:111),
+ * `input + eps * c_out` (:114), the CFG combine (model_k_diffusion.py:1162-1166) and the 3-5 elementwise launches
+ * of k_diffusion.sampling.sample_dpmpp_2m (un-vendored), by ONE launch:
+ *
+ *   D      = x - sigma * (eps_u + guidance * (eps_c - eps_u))          eps = [eps_u(n_img rows); eps_c(n_img rows)]
+ *   x      = a * x + b * D + c * old ;   old = D                       (in place; fp32 math, one fp16 rounding each)
+ *   x_in   = [x; x] * c_in_next ;  t_buf[0 .. 2 n_img) = t_next ;  sigma_buf[0] = sigma_next
+ *
+ * x, old: fp16 [n_img, chw]; eps, x_in: fp16 [2 n_img, chw]; t_buf fp32 [2 n_img]; sigma_buf fp32 [1].
+ * dsc_prepare_unet_input does only the last line (before the first step).  chw % 8 == 0, 16-byte aligned pointers.
+ */
+int dsc_prepare_unet_input(const void* x, float c_in, float t, float sigma,
+                           void* x_in, float* t_buf, float* sigma_buf, int n_img, int chw, int dtype, void* stream);
+int dsc_cfg_dpmpp2m_step(void* x, const void* eps, void* old, float sigma, float guidance,
+                         float a, float b, float c, float c_in_next, float t_next, float sigma_next,
+                         void* x_in, float* t_buf, float* sigma_buf, int n_img, int chw, int dtype, void* stream);
+/* out = a*x + b*denoised + c*old  (old may be NULL when c == 0): the sampler update alone, for callers that keep
+ * the reference's `sampler(model_fn, x, sigmas=...)` control flow.  n elements, n % 8 == 0. */
+int dsc_dpmpp2m_update(const void* x, const void* denoised, const void* old, float a, float b, float c,
+                       void* out, int64_t n, int dtype, void* stream);
+
+/*
+ * GroupNorm (+ optional SiLU) over NCHW fp16 - replaces `GroupNorm(32, eps)` -> `SiLU` pairs of the UNet
+ * (u_net_condition_modify.py:465-470,1304-1306 and diffusers ResnetBlock2D / Transformer2DModel norms; SURVEY.md 2b
+ * row 12).  y[b,c,:,:] = act((x - mean_bg) * rstd_bg * gamma[c] + beta[c]), statistics in fp32/fp64 over the
+ * (C/groups) * hw elements of group g of row b (biased variance, as torch).  Two launches (partial sums, apply);
+ * workspace from dsc_groupnorm_workspace_bytes(), no initialisation needed.  gamma/beta fp16 [C].
+ * Requirements: C % groups == 0, hw % 8 == 0, 16-byte aligned x / y.
+ */
+size_t dsc_groupnorm_workspace_bytes(int B, int C, int hw, int groups);
+int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, const void* beta,
+                       int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* GEGLU of the transformer feed-forward (diffusers GEGLU): y[r, j] = x[r, j] * gelu(x[r, n + j]), exact erf gelu.
+ * x fp16 [rows, 2n] contiguous, y fp16 [rows, n]; n % 8 == 0. */
+int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

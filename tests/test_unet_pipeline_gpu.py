@@ -1,0 +1,152 @@
+"""GPU parity of the UNet-step kernels (GroupNorm+SiLU, GEGLU, fused sampler step), of the UNet forward and of
+the 25-step denoising loop against the CPU oracle (torch fp32 restatement) on identical weights and inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from inputs import FakeTokenizer, prompt_ids, rect_map
+from oracle import k_diffusion_ref as kd
+from oracle import unet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from diffusionspatialcontrol_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("B,C,h,w,G,act,eps", [(2, 320, 64, 64, 32, True, 1e-5), (2, 2560, 16, 16, 32, True, 1e-5),
+                                               (2, 1280, 8, 8, 32, False, 1e-6), (1, 32, 4, 4, 8, True, 1e-5),
+                                               (16, 640, 32, 32, 32, True, 1e-5), (3, 96, 6, 4, 8, False, 1e-5)])
+def test_groupnorm_silu(ops, B, C, h, w, G, act, eps):
+    g = torch.Generator().manual_seed(B * C + h)
+    x = (torch.randn(B, C, h, w, generator=g) * 1.7 + 0.6).half()
+    gamma, beta = (torch.randn(C, generator=g) * 0.5 + 1).half(), (torch.randn(C, generator=g) * 0.3).half()
+    ref = F.group_norm(x.float(), G, gamma.float(), beta.float(), eps)
+    ref = F.silu(ref) if act else ref
+    y = ops.groupnorm_silu(x.cuda(), G, gamma.cuda(), beta.cuda(), eps, act)
+    err = (y.float().cpu() - ref).abs()
+    assert err.max().item() < 4e-3 * max(1.0, ref.abs().max().item()), err.max().item()   # fp16 output rounding
+    assert err.mean().item() < 4e-4
+    assert torch.equal(y, ops.groupnorm_silu(x.cuda(), G, gamma.cuda(), beta.cuda(), eps, act))   # reproducible
+
+
+def test_geglu(ops):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 100, 2 * 1280, generator=g) * 2).half()
+    hid, gate = x.float().chunk(2, dim=-1)
+    ref = hid * F.gelu(gate)
+    y = ops.geglu(x.cuda()).float().cpu()
+    assert (y - ref).abs().max().item() < 8e-3 and (y - ref).abs().mean().item() < 3e-4
+
+
+def test_sampler_kernels(ops):
+    g = torch.Generator().manual_seed(11)
+    n, shp = 3, (3, 4, 16, 16)
+    x = (torch.randn(shp, generator=g) * 10).half()
+    eps = torch.randn((2 * n,) + shp[1:], generator=g).half()
+    old = torch.randn(shp, generator=g).half()
+    sigma, gs, a, b, c, cin, tn, sn = 3.17, 7.5, 0.8, 0.25, -0.05, 0.3, 412.5, 2.55
+    xi, tb, sb = torch.zeros(2 * n, *shp[1:], dtype=torch.half).cuda(), torch.zeros(2 * n).cuda(), torch.zeros(1).cuda()
+    ops.prepare_unet_input(x.cuda(), 0.123, 999.0, 14.6, xi, tb, sb)
+    assert (xi.float().cpu() - torch.cat([x, x]).float() * 0.123).abs().max() < 2e-3
+    assert tb.tolist() == [999.0] * (2 * n) and abs(sb.item() - 14.6) < 1e-6
+    xd, od = x.cuda().clone(), old.cuda().clone()
+    ops.cfg_dpmpp2m_step(xd, eps.cuda(), od, sigma, gs, a, b, c, cin, tn, sn, xi, tb, sb)
+    eu, ec = eps.float().chunk(2)
+    D = x.float() - sigma * (eu + gs * (ec - eu))
+    xn = a * x.float() + b * D + c * old.float()
+    assert (od.float().cpu() - D).abs().max() < 0.04            # |D| ~ 60: fp16 ulp 0.03
+    assert (xd.float().cpu() - xn).abs().max() < 0.02
+    assert (xi.float().cpu() - torch.cat([xn, xn]) * cin).abs().max() < 0.01
+    assert tb.tolist() == [tn] * (2 * n) and abs(sb.item() - sn) < 1e-6
+    out = ops.dpmpp2m_update(x.cuda(), eps[:n].cuda(), old.cuda(), a, b, c)
+    assert (out.float().cpu() - (a * x.float() + b * eps[:n].float() + c * old.float())).abs().max() < 0.01
+    out = ops.dpmpp2m_update(x.cuda(), eps[:n].cuda(), None, a, b, 0.0)
+    assert (out.float().cpu() - (a * x.float() + b * eps[:n].float())).abs().max() < 0.01
+
+
+def _tiny_setup(n_img=1, seed=0):
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
+    torch.manual_seed(seed)
+    cfg = UNetConfig.tiny()
+    unet = UNet2DConditionModel(cfg).half()
+    sd = {k: v.clone() for k, v in unet.state_dict().items()}      # fp16-representable weights shared with the oracle
+    g = torch.Generator().manual_seed(7)
+    text = torch.randn(2 * n_img, 77, cfg.cross_attention_dim, generator=g).half()
+    return cfg, unet.cuda(), sd, text
+
+
+def _region_state(W=128, H=128, n_img=1):
+    from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
+    import types
+    P = "a photo of a red apple on a wooden table near a blue vase"
+    ids = [prompt_ids("blurry"), prompt_ids(P)]
+    state = {"red apple": {"map": rect_map(H, W, 0, 0, 1, 2), "weight": 0.5, "mask_outsides": 0.0},
+             "blue vase": {"map": rect_map(H, W, 1, 0, 2, 1), "weight": 0.8, "mask_outsides": 0.2}}
+    pipe = types.SimpleNamespace(tokenizer=FakeTokenizer(), unet=types.SimpleNamespace(down_blocks=[0] * 4),
+                                 vae_scale_factor=8, do_classifier_free_guidance=True)
+    return state, ids, encode_region_map(pipe, state, W, H, n_img, text_ids=ids)
+
+
+def test_unet_forward_matches_oracle(ops):
+    cfg, unet, sd, text = _tiny_setup()
+    _, _, rs = _region_state()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 16, 16, generator=g).half()
+    t = torch.tensor([731.25, 731.25])
+    sigma = torch.tensor([4.0], device="cuda")
+    rp = {"region_state": rs, "sigma": sigma, "weight_func": lambda w, s, qk: w * s * qk.std()}
+    out = unet(x.cuda(), t.cuda(), text.cuda(), cross_attention_kwargs={"region_prompt": rp}).sample.float().cpu()
+    rp_o = {"region_state": rs, "sigma": 4.0, "weight_func": None}
+    ref = unet_ref.unet_forward(sd, cfg, x.float(), t, text.float(), region_prompt=rp_o)
+    scale = ref.abs().max().item()
+    err = (out - ref).abs()
+    # 60+ fp16 layers deep: relative 1e-2 of the output range, mean 2e-3
+    assert err.max().item() < 1e-2 * scale + 1e-3, (err.max().item(), scale)
+    assert err.mean().item() < 2e-3 * scale
+    # the region bias is live: without it the output differs
+    out0 = unet(x.cuda(), t.cuda(), text.cuda()).sample.float().cpu()
+    assert (out0 - out).abs().max().item() > 10 * err.max().item() or (out0 - out).abs().max().item() > 1e-2 * scale
+
+
+@pytest.mark.parametrize("n_img", [1, 2])
+def test_denoise_loop_fused_protocol_oracle(ops, n_img):
+    """6-step DPM++ 2M Karras loop on the tiny UNet: fused (graph) == protocol (closure) ~= CPU oracle."""
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    cfg, unet, sd, text = _tiny_setup(n_img)
+    state, ids, rs = _region_state(n_img=1)
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    g = torch.Generator().manual_seed(1000)
+    lat = torch.randn(n_img, 4, 16, 16, generator=g).half()
+    pe, ne = text[n_img:n_img + 1], text[:1]
+    kw = dict(height=128, width=128, num_inference_steps=6, guidance_scale=7.5, latents=lat.clone(), output_type="latent",
+              region_map_state=state, sampler_name="sample_dpmpp_2m", sampler_opt={"scheduler": "karras"},
+              prompt_embeds=pe.repeat(1, 1, 1), negative_prompt_embeds=ne, text_input_ids=ids,
+              num_images_per_prompt=n_img)
+    if n_img > 1:
+        kw["latents"] = lat.clone()
+    fused = pipe.txt2img(None, fused=True, **kw)[0].float().cpu()
+    proto = pipe.txt2img(None, fused=False, **kw)[0].float().cpu()
+    sig = pipe.get_sigmas(6, {"scheduler": "karras"}).half().float().tolist()
+    text_rows = torch.cat([ne.repeat(n_img, 1, 1), pe.repeat(n_img, 1, 1)]).float()
+    rs_rows = {L: t for L, t in rs.items()}
+    ref = unet_ref.denoise_loop(sd, cfg, lat.float() * math.sqrt(sig[0] ** 2 + 1), sig, text_rows, rs_rows, 7.5)
+    scale = ref.abs().max().item()
+    assert torch.isfinite(fused).all()
+    assert (fused - proto).abs().max().item() < 2e-2 * scale      # same kernels, different rounding points
+    assert (fused - ref).abs().max().item() < 4e-2 * scale, ((fused - ref).abs().max().item(), scale)
+    assert (fused - ref).abs().mean().item() < 6e-3 * scale
+    # replays are deterministic
+    again = pipe.txt2img(None, fused=True, **kw)[0].float().cpu()
+    assert torch.equal(fused, again)
+    if n_img == 2:      # images are independent: image 0 of the pair equals the single-image run (per-image std groups)
+        kw1 = dict(kw, latents=lat[:1].clone(), num_images_per_prompt=1)
+        single = pipe.txt2img(None, fused=True, **kw1)[0].float().cpu()
+        assert (single[0] - fused[0]).abs().max().item() < 2e-2 * scale
