@@ -81,6 +81,48 @@ __global__ __launch_bounds__(kT) void gn_apply(GnParams p) {
     }
 }
 
+// generic-shape fallback (hw % 8 != 0, e.g. the 2x2 / 4x4 levels of toy UNets): one element per lane-step
+__global__ __launch_bounds__(kT) void gn_stats_scalar(GnParams p, long long n, long long chunk) {
+    __shared__ double red[2 * (kT / 64)];
+    const int bg = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit;
+    const half_t* base = p.x + (long long)bg * n;
+    const long long e0 = (long long)sp * chunk, e1 = min(e0 + chunk, n);
+    double d1 = 0.0, d2 = 0.0;
+    for (long long e = e0 + threadIdx.x; e < e1; e += kT) { const double f = (double)(float)base[e]; d1 += f; d2 += f * f; }
+    d1 = wave_sum_f64(d1); d2 = wave_sum_f64(d2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * wave] = d1; red[2 * wave + 1] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int w = 0; w < kT / 64; ++w) { a1 += red[2 * w]; a2 += red[2 * w + 1]; }
+        double* dst = p.partials + ((long long)bg * p.nsplit + sp) * 2;
+        dst[0] = a1; dst[1] = a2;
+    }
+}
+
+__global__ __launch_bounds__(kT) void gn_apply_scalar(GnParams p, long long n, long long chunk) {
+    const int bg = blockIdx.x / p.nsplit, sp = blockIdx.x % p.nsplit;
+    const int g = bg % p.groups;
+    const double* src = p.partials + (long long)bg * p.nsplit * 2;
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = 0; i < p.nsplit; ++i) { a1 += src[2 * i]; a2 += src[2 * i + 1]; }
+    const double mean_d = a1 / (double)n;
+    double var = a2 / (double)n - mean_d * mean_d;
+    var = var > 0.0 ? var : 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+    const half_t* base = p.x + (long long)bg * n;
+    half_t* out = p.y + (long long)bg * n;
+    const long long e0 = (long long)sp * chunk, e1 = min(e0 + chunk, n);
+    for (long long e = e0 + threadIdx.x; e < e1; e += kT) {
+        const int c = g * p.cpg + (int)(e / p.hw);
+        const float ga = (float)p.gamma[c] * rstd, be = (float)p.beta[c] - mean * ga;
+        float f = (float)base[e] * ga + be;
+        if (p.silu) f = f / (1.f + __expf(-f));
+        out[e] = (half_t)f;
+    }
+}
+
 void plan(GnParams& p, int B) {
     const int ng = B * p.groups;
     int ns = (1024 + ng - 1) / ng;                             // aim for >= 1024 workgroups
@@ -125,7 +167,7 @@ extern "C" int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, con
                                   int groups, float eps, int apply_silu, int dtype, void* workspace,
                                   size_t workspace_bytes, void* stream) {
     if (!x || !y || !gamma || !beta || B <= 0 || C <= 0 || hw <= 0 || groups <= 0 || C % groups) return DSC_ERR_BAD_ARG;
-    if (dtype != DSC_F16 || hw % 8 != 0 || !al16(x) || !al16(y)) return DSC_ERR_UNSUPPORTED;
+    if (dtype != DSC_F16 || !al16(x) || !al16(y)) return DSC_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < dsc_groupnorm_workspace_bytes(B, C, hw, groups) ||
         (reinterpret_cast<uintptr_t>(workspace) & 7))
         return DSC_ERR_WORKSPACE;
@@ -136,8 +178,16 @@ extern "C" int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, con
     p.C = C; p.hw = hw; p.groups = groups; p.cpg = C / groups;
     p.n8 = (long long)p.cpg * hw / 8;
     p.eps = eps; p.silu = apply_silu;
-    plan(p, B);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hw % 8 != 0) {                       // scalar fallback: correctness path for odd spatial sizes
+        const long long n = (long long)p.cpg * hw;
+        p.nsplit = 1;
+        const dim3 grid(B * groups), block(kT);
+        hipLaunchKernelGGL(gn_stats_scalar, grid, block, 0, st, p, n, n);
+        hipLaunchKernelGGL(gn_apply_scalar, grid, block, 0, st, p, n, n);
+        return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+    }
+    plan(p, B);
     const dim3 grid(B * groups * p.nsplit), block(kT);
     hipLaunchKernelGGL(gn_stats, grid, block, 0, st, p);
     hipLaunchKernelGGL(gn_apply, grid, block, 0, st, p);

@@ -73,6 +73,34 @@ class UNetConfig:
                           norm_num_groups=8, time_embed_dim=128, sample_size=16)
 
 
+class Conv1x1(nn.Conv2d):
+    """1x1 convolution run as a GEMM over channels (hipBLASLt) instead of a MIOpen convolution: same parameters and
+    state_dict keys as nn.Conv2d(cin, cout, 1).  MIOpen's 1x1 kernels at small spatial sizes accumulate with atomics
+    (measured: run-to-run differences of 3e-2 at 128->64 @ 2x2), the GEMM is bit-reproducible."""
+
+    def __init__(self, cin, cout):
+        super().__init__(cin, cout, 1)
+
+    def forward(self, x, residual=None):
+        b, c, h, w = x.shape
+        w2 = self.weight.view(self.out_channels, c)
+        y = torch.matmul(w2, x.reshape(b, c, h * w))
+        y = y + self.bias.view(1, -1, 1)
+        y = y.view(b, self.out_channels, h, w)
+        return y if residual is None else y + residual
+
+    def tokens(self, x):
+        """[B, C, h, w] -> projected tokens [B, h*w, Cout] without an NCHW->NLC copy"""
+        b, c, h, w = x.shape
+        return F.linear(x.reshape(b, c, h * w).transpose(1, 2), self.weight.view(self.out_channels, c), self.bias)
+
+    def from_tokens(self, t, h, w, residual):
+        """tokens [B, L, C] -> [B, Cout, h, w] (+ residual)"""
+        b, L, c = t.shape
+        y = torch.matmul(self.weight.view(self.out_channels, c), t.transpose(1, 2)) + self.bias.view(1, -1, 1)
+        return y.view(b, self.out_channels, h, w) + residual
+
+
 class GroupNormAct(nn.GroupNorm):
     """GroupNorm optionally fused with SiLU (HIP kernel on the GPU)."""
 
@@ -188,8 +216,8 @@ class Transformer2DModel(nn.Module):
             self.proj_in = nn.Linear(channels, channels)
             self.proj_out = nn.Linear(channels, channels)
         else:
-            self.proj_in = nn.Conv2d(channels, channels, 1)
-            self.proj_out = nn.Conv2d(channels, channels, 1)
+            self.proj_in = Conv1x1(channels, channels)
+            self.proj_out = Conv1x1(channels, channels)
         self.transformer_blocks = nn.ModuleList(
             [BasicTransformerBlock(channels, heads, channels // heads, cross_attention_dim) for _ in range(depth)])
 
@@ -200,14 +228,12 @@ class Transformer2DModel(nn.Module):
         if self.use_linear_projection:
             x = self.proj_in(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
         else:
-            x = self.proj_in(x).permute(0, 2, 3, 1).reshape(b, h * w, c)
+            x = self.proj_in.tokens(x)
         for blk in self.transformer_blocks:
             x = blk(x, encoder_hidden_states, cross_attention_kwargs)
         if self.use_linear_projection:
-            x = self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2)
-        else:
-            x = self.proj_out(x.reshape(b, h, w, c).permute(0, 3, 1, 2))
-        return x + res
+            return self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2) + res
+        return self.proj_out.from_tokens(x, h, w, res)
 
 
 class ResnetBlock2D(nn.Module):
@@ -218,13 +244,13 @@ class ResnetBlock2D(nn.Module):
         self.time_emb_proj = nn.Linear(temb_dim, cout)
         self.norm2 = GroupNormAct(groups, cout, eps, act=True)
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
-        self.conv_shortcut = nn.Conv2d(cin, cout, 1) if cin != cout else None
+        self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
 
     def forward(self, x, temb_act):
         h = self.conv1(self.norm1(x))
         h = h + self.time_emb_proj(temb_act)[:, :, None, None]
         h = self.conv2(self.norm2(h))
-        return (self.conv_shortcut(x) if self.conv_shortcut is not None else x) + h
+        return self.conv_shortcut(x, residual=h) if self.conv_shortcut is not None else x + h
 
 
 class Downsample2D(nn.Module):

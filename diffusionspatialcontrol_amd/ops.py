@@ -10,9 +10,6 @@ FLAG_REF_FP16_ROUNDING = 1
 FLAG_BIAS_IS_FINAL = 2
 FLAG_REUSE_STATS = 4
 
-_WS = {}
-
-
 def _stream_ptr(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -28,14 +25,10 @@ def _require_gpu(*ts):
 
 
 def _workspace(device, nbytes):
-    """A per-(device, stream) fp64 scratch buffer; grows monotonically, never shrinks (graph-capture safe
-    once warmed up at the largest size)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _WS.get(key)
-    if buf is None or buf.numel() * 8 < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 16) // 8 + 1, dtype=torch.float64, device=device)
-        _WS[key] = buf
-    return buf
+    """fp64 scratch for one call, from torch's caching allocator.  Deliberately NOT cached across calls: inside a
+    HIP-graph capture the allocation must belong to that graph's private pool, and a buffer remembered from an
+    earlier (since destroyed) capture would alias live activations of the next one."""
+    return torch.empty(max(nbytes, 16) // 8 + 1, dtype=torch.float64, device=device)
 
 
 def _blhd_strides(t, layout):

@@ -122,7 +122,7 @@ int dsc_dpmpp2m_update(const void* x, const void* denoised, const void* old, flo
  * row 12).  y[b,c,:,:] = act((x - mean_bg) * rstd_bg * gamma[c] + beta[c]), statistics in fp32/fp64 over the
  * (C/groups) * hw elements of group g of row b (biased variance, as torch).  Two launches (partial sums, apply);
  * workspace from dsc_groupnorm_workspace_bytes(), no initialisation needed.  gamma/beta fp16 [C].
- * Requirements: C % groups == 0, hw % 8 == 0, 16-byte aligned x / y.
+ * Requirements: C % groups == 0, 16-byte aligned x / y (hw % 8 != 0 takes a scalar-load path).
  */
 size_t dsc_groupnorm_workspace_bytes(int B, int C, int hw, int groups);
 int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, const void* beta,
