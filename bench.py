@@ -45,8 +45,10 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--regions", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--nondeterministic-conv", action="store_true",
+                    help="let MIOpen pick split-K (atomic) convolution kernels: faster on some shapes, not bit-reproducible")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=2)
+    ap.add_argument("--cpu-sample-steps", type=int, default=1)
     return ap.parse_args()
 
 
@@ -127,10 +129,28 @@ def roofline_region_xattn(dev, n_img):
             "stats_plus_fwd_us": round(pair * 1e3, 2)}
 
 
+def host_cores():
+    """cores this process may actually use (the GPU box exposes 256 logical CPUs but grants a share of them)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count()
+    quota = None
+    try:                                        # cgroup v2 cpu.max = "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:  # noqa: BLE001
+        pass
+    n = min(n, quota) if quota else n
+    return max(1, min(n, int(os.environ.get("DSC_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sample_steps, total_steps):
     """oracle on the host cores: `sample_steps` of the `total_steps` denoising steps of the same image, extrapolated"""
     from oracle import unet_ref
-    torch.set_num_threads(os.cpu_count())
+    cores = host_cores()
+    torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     sig = sigmas.float().cpu().tolist()
     lat = latents.float().cpu() * math.sqrt(sig[0] ** 2 + 1)
@@ -138,7 +158,7 @@ def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sampl
     unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), region_state, guidance, steps_limit=sample_steps)
     dt = time.perf_counter() - t0
     per_image = dt / sample_steps * total_steps
-    return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} of {total_steps} denoising steps of one 512x512 image through the fp32 torch oracle "
                       f"({dt:.1f} s), scaled x{total_steps}/{sample_steps}",
             "seconds_per_image_extrapolated": round(per_image, 1)}
@@ -164,6 +184,7 @@ def main():
     from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
     from diffusionspatialcontrol_amd.parallel import broadcast_generation_inputs, shard_image_indices
     ops.GRAPHS_ENABLED = not a.no_graph
+    torch.backends.cudnn.deterministic = not a.nondeterministic_conv
 
     cfg = UNetConfig.sd15()
     torch.manual_seed(0)

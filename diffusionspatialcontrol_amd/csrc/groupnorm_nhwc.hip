@@ -1,0 +1,197 @@
+// GroupNorm (+SiLU, + fused per-(b,c) add) over channels-last fp16 activations (dsc_groupnorm_silu_nhwc).
+//
+// In NHWC a row (one pixel) holds all C channels contiguously, so a group is cpg = C/groups adjacent halves of
+// EVERY row: the statistics are column sums.  A workgroup owns a chunk of rows of one image and ALL groups:
+// thread t reads the fixed 16-byte channel vector c8 = t % (C/8) of rows slice, slice+k, ... (k = row slices per
+// workgroup), so every load/store is a coalesced 16-byte access and the per-channel constants stay in registers.
+//   launch 1 gn_nhwc_stats : per-thread channel sums -> LDS [k][C] -> per-channel -> per-group (sum, sumsq) in
+//                            fp64 -> partials[b][chunk][g]
+//   launch 2 gn_nhwc_apply : re-adds the chunk partials (fixed order), folds mean/rstd/gamma/beta(/add) into one
+//                            scale+shift per channel, streams its rows: y = silu(x*sc + sh)
+// HBM-bound: algorithmic bytes = 2 * B*hw*C*2 (read + write); the second read hits L2 / Infinity Cache.
+#include "dsc_common.h"
+#include "dsc_hip.h"
+
+namespace {
+
+constexpr int kMaxT = 512;
+
+struct GnN {
+    const half_t* x; half_t* y; const half_t* gamma; const half_t* beta; const half_t* add;
+    double* partials;            // [B][nchunk][G][2]
+    int B, HW, C, G, cpg, cv, k, nchunk, rows;
+    long long add_stride;
+    float eps; int silu;
+};
+
+__global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ssum = reinterpret_cast<float*>(smem);            // [k][C]
+    float* ssq = ssum + p.k * p.C;                           // [k][C]
+    const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
+    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
+    const int r0 = chunk * p.rows, r1 = min(r0 + p.rows, p.HW);
+    float s[8], q[8], ad[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; ad[j] = 0.f; }
+    if (p.add) {
+        const h8_t a = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ad[j] = (float)a[j];
+    }
+    const half_t* base = p.x + (long long)b * p.HW * p.C + c8 * 8;
+    for (int row = r0 + slice; row < r1; row += p.k) {
+        const h8_t v = *reinterpret_cast<const h8_t*>(base + (long long)row * p.C);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + ad[j]; s[j] += f; q[j] += f * f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[slice * p.C + c8 * 8 + j] = s[j]; ssq[slice * p.C + c8 * 8 + j] = q[j]; }
+    __syncthreads();
+    // per-group totals: thread g sums its cpg channels over the k slices (fixed order), in fp64
+    if (threadIdx.x < p.G) {
+        const int g = threadIdx.x;
+        double a1 = 0.0, a2 = 0.0;
+        for (int sl = 0; sl < p.k; ++sl)
+            for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += (double)ssum[sl * p.C + c]; a2 += (double)ssq[sl * p.C + c]; }
+        double* dst = p.partials + (((long long)b * p.nchunk + chunk) * p.G + g) * 2;
+        dst[0] = a1; dst[1] = a2;
+    }
+}
+
+__global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
+    __shared__ float mean_s[64], rstd_s[64];
+    __shared__ double red[kMaxT * 2];
+    const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
+    {   // all threads re-add the chunk partials: thread (g, part) takes chunks part, part+np, ...; fixed order
+        const int T = blockDim.x, np = T / p.G;              // T >= G always (cv*k >= 32 for C >= 256; checked in plan)
+        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+        double a1 = 0.0, a2 = 0.0;
+        if (part < np) {
+            const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
+            for (int i = part; i < p.nchunk; i += np) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+        }
+        red[2 * threadIdx.x] = a1; red[2 * threadIdx.x + 1] = a2;
+        __syncthreads();
+        if (threadIdx.x < p.G) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int q = 0; q < np; ++q) { t1 += red[2 * (q * p.G + g)]; t2 += red[2 * (q * p.G + g) + 1]; }
+            const double n = (double)p.HW * p.cpg;
+            const double m = t1 / n;
+            double var = t2 / n - m * m;
+            var = var > 0.0 ? var : 0.0;
+            mean_s[g] = (float)m;
+            rstd_s[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+    }
+    __syncthreads();
+    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
+    float sc[8], sh[8];
+    {
+        const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + c8 * 8);
+        const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + c8 * 8);
+        h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c8 * 8 + j) / p.cpg;
+            sc[j] = (float)ga[j] * rstd_s[g];
+            sh[j] = (float)be[j] + ((float)ad[j] - mean_s[g]) * sc[j];
+        }
+    }
+    const int r0 = chunk * p.rows, r1 = min(r0 + p.rows, p.HW);
+    const long long off = (long long)b * p.HW * p.C + c8 * 8;
+    for (int row = r0 + slice; row < r1; row += p.k) {
+        const h8_t v = *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C);
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)v[j] * sc[j] + sh[j];
+            if (p.silu) f = f / (1.f + __expf(-f));
+            o[j] = (half_t)f;
+        }
+        *reinterpret_cast<h8_t*>(p.y + off + (long long)row * p.C) = o;
+    }
+}
+
+bool plan(GnN& p) {
+    p.cv = p.C / 8;
+    if (p.C % 8 != 0 || p.cv > kMaxT || p.G > 64 || p.C % p.G != 0) return false;
+    p.cpg = p.C / p.G;
+    p.k = 256 / p.cv;
+    if (p.k < 1) p.k = 1;
+    while (p.cv * p.k < p.G) ++p.k;                          // the partial re-add needs >= G threads
+    int target = 768 / p.B;                                  // ~3 workgroups per CU
+    if (target < 1) target = 1;
+    if (target > 128) target = 128;                          // bounds the per-workgroup partial re-add
+    int min_rows = 2 * p.k;                                  // at least two rows per thread
+    int nchunk = (p.HW + min_rows - 1) / min_rows;
+    if (nchunk > target) nchunk = target;
+    if (nchunk < 1) nchunk = 1;
+    p.rows = (p.HW + nchunk - 1) / nchunk;
+    p.nchunk = (p.HW + p.rows - 1) / p.rows;
+    return true;
+}
+
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+__global__ __launch_bounds__(256) void add_bias_kernel(const half_t* a, const half_t* b, const half_t* bias, half_t* out,
+                                                       long long n8, int cv) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const h8_t va = *reinterpret_cast<const h8_t*>(a + i * 8);
+        const h8_t vb = *reinterpret_cast<const h8_t*>(b + i * 8);
+        h8_t bi = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (bias) bi = *reinterpret_cast<const h8_t*>(bias + (i % cv) * 8);
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)va[j] + (float)vb[j] + (float)bi[j]);
+        *reinterpret_cast<h8_t*>(out + i * 8) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int dsc_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t rows, int C,
+                                     int dtype, void* stream) {
+    if (!a || !b || !out || rows <= 0 || C <= 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16 || C % 8 != 0 || !al16(a) || !al16(b) || !al16(out) || (bias && !al16(bias))) return DSC_ERR_UNSUPPORTED;
+    const long long n8 = rows * (C / 8);
+    long long g = (n8 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(add_bias_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const half_t*>(a), static_cast<const half_t*>(b), static_cast<const half_t*>(bias),
+                       static_cast<half_t*>(out), n8, C / 8);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}
+
+extern "C" size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int groups) {
+    GnN p{};
+    p.B = B; p.C = C; p.HW = hw; p.G = groups;
+    if (B <= 0 || C <= 0 || hw <= 0 || groups <= 0 || !plan(p)) return 0;
+    return (size_t)B * p.nchunk * groups * 2 * sizeof(double);
+}
+
+extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, const void* add,
+                                       int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !y || !gamma || !beta || B <= 0 || C <= 0 || hw <= 0 || groups <= 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
+    GnN p{};
+    p.B = B; p.C = C; p.HW = hw; p.G = groups;
+    if (!plan(p)) return DSC_ERR_UNSUPPORTED;
+    if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta) || (add && (!al16(add) || add_row_stride % 8 != 0 || add_row_stride < C)))
+        return DSC_ERR_UNSUPPORTED;
+    const size_t need = (size_t)B * p.nchunk * groups * 2 * sizeof(double);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;
+    p.x = static_cast<const half_t*>(x); p.y = static_cast<half_t*>(y);
+    p.gamma = static_cast<const half_t*>(gamma); p.beta = static_cast<const half_t*>(beta);
+    p.add = static_cast<const half_t*>(add);
+    p.add_stride = add_row_stride;
+    p.partials = static_cast<double*>(workspace);
+    p.eps = eps; p.silu = apply_silu;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(B * p.nchunk), block(p.cv * p.k);
+    hipLaunchKernelGGL(gn_nhwc_stats, grid, block, (size_t)2 * p.k * C * sizeof(float), st, p);
+    hipLaunchKernelGGL(gn_nhwc_apply, grid, block, 0, st, p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}

@@ -165,19 +165,33 @@ class _RegionProcessor:
             raise NotImplementedError("attention masks are not on the hot path (app.py never passes one)")
         if attn.group_norm is not None:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
-        query = attn.to_q(hidden_states)
         is_self = encoder_hidden_states is None
-        if is_self:
-            encoder_hidden_states = hidden_states
-        elif attn.norm_cross:
-            encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
-        key = attn.to_k(encoder_hidden_states)
-        value = attn.to_v(encoder_hidden_states)
-        B, L, C = query.shape
         H = attn.heads
-        d = C // H
-        S = key.shape[1]
-        q4, k4, v4 = query.view(B, L, H, d), key.view(B, S, H, d), value.view(B, S, H, d)
+        fused_qkv = getattr(attn, "qkv_weight", None)
+        if is_self and fused_qkv is not None and attn.to_q.bias is None:
+            # self-attention: q, k, v from ONE [3C, C] GEMM; the three [B, L, H, d] operands are strided views of it
+            B, L, _ = hidden_states.shape
+            qkv = F.linear(hidden_states, fused_qkv())
+            C = qkv.shape[-1] // 3
+            d = C // H
+            S = L
+            q4, k4, v4 = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+        else:
+            query = attn.to_q(hidden_states)
+            if is_self:
+                encoder_hidden_states = hidden_states
+            elif attn.norm_cross:
+                encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
+            cache = getattr(attn, "kv_cache", None)
+            if cache is not None and cache["src"] is encoder_hidden_states:
+                key, value = cache["k"], cache["v"]          # text K/V: once per generation, not once per step
+            else:
+                key = attn.to_k(encoder_hidden_states)
+                value = attn.to_v(encoder_hidden_states)
+            B, L, C = query.shape
+            d = C // H
+            S = key.shape[1]
+            q4, k4, v4 = query.view(B, L, H, d), key.view(B, S, H, d), value.view(B, S, H, d)
         sc = attn.scale if self.honours_attn_scale else None
         if is_xattn and isinstance(region_prompt["region_state"], dict):
             w = region_prompt["region_state"][img_sequence_length]          # KeyError when L is not a level (:481)

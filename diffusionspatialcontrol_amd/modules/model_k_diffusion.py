@@ -100,6 +100,7 @@ class StableDiffusionPipeline:
         self.k_diffusion_model = CompVisDenoiser(ModelWrapper(unet, self.scheduler.alphas_cumprod))
         self.k_diffusion_model.to(unet.device)
         self._graphs = {}
+        self._drop_text_kv()
 
     def get_scheduler(self, scheduler_type: str):
         """reference :143-146 resolves the name in `k_diffusion.sampling`; here in the build's own sampling module"""
@@ -241,6 +242,7 @@ class StableDiffusionPipeline:
         st = self._graphs.get(key)
         if st is not None:
             st["text"].copy_(text)
+            self._refresh_text_kv(st["text"])
             return st
         dev, dt = text.device, text.dtype
         rows = 2 * n_img
@@ -250,6 +252,7 @@ class StableDiffusionPipeline:
             "sigma": torch.ones(1, device=dev, dtype=torch.float32),
             "text": text.clone(),
         }
+        self._refresh_text_kv(st["text"])
         kw = dict(cross_attention_kwargs)
         kw["region_prompt"] = {"region_state": region_state, "sigma": st["sigma"], "weight_func": weight_func,
                                "n_std_groups": n_img}
@@ -273,6 +276,27 @@ class StableDiffusionPipeline:
             st["run"] = g.replay
         self._graphs = {key: st}                 # keep one: the tables/text of the previous generation are dead
         return st
+
+    def _refresh_text_kv(self, text):
+        """K/V projections of the text for every cross-attention layer, once per generation (they are step-invariant;
+        the reference recomputes them in all 16 layers x 25 steps).  Written IN PLACE into the buffers the captured
+        graph reads."""
+        from .u_net_condition_modify import Attention
+        for m in self.unet.modules():
+            if isinstance(m, Attention) and m.is_cross_attention:
+                k, v = m.to_k(text), m.to_v(text)
+                c = m.kv_cache
+                if c is not None and c["src"] is text and c["k"].shape == k.shape:
+                    c["k"].copy_(k)
+                    c["v"].copy_(v)
+                else:
+                    m.kv_cache = {"src": text, "k": k, "v": v}
+
+    def _drop_text_kv(self):
+        from .u_net_condition_modify import Attention
+        for m in self.unet.modules():
+            if isinstance(m, Attention):
+                m.kv_cache = None
 
     def _denoise_fused(self, latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                        cross_attention_kwargs, start_time, timeout):

@@ -11,8 +11,10 @@ What is kept from the reference surface:
     diffusers SD1.5 / SDXL-base UNet state_dict loads with `load_state_dict`
   * `UNet2DConditionLoadersMixin_modify`, the symbol the reference imports but never defines (:23)
 
-Device work: convolutions and projection GEMMs go to MIOpen / hipBLASLt through torch (plain library
-GEMMs); GroupNorm+SiLU, self-attention, region cross-attention run in libdsc_hip.so (see ..ops).
+Device work: activations are kept channels-last (NHWC) end to end - the same bytes as the transformer's token-major
+[B, h*w, C] view - so MIOpen's NHWC implicit-GEMM convolutions and the hipBLASLt projection GEMMs (plain library
+GEMMs, reached through torch) need no layout transposes; GroupNorm+SiLU(+time-embedding add), GEGLU,
+self-attention and region cross-attention run in libdsc_hip.so (see ..ops).
 """
 import inspect
 import math
@@ -73,43 +75,60 @@ class UNetConfig:
                           norm_num_groups=8, time_embed_dim=128, sample_size=16)
 
 
+def _derived(module, key, deps, build):
+    """A tensor derived from parameters (concatenated / summed weights), cached on the module and rebuilt when any
+    source parameter object or its in-place version changes.  Derived tensors are not parameters: state_dict keys
+    stay the diffusers ones."""
+    sig = tuple((id(t), t._version) for t in deps)
+    hit = module.__dict__.get("_derived_" + key)
+    if hit is None or hit[0] != sig:
+        with torch.no_grad():
+            hit = (sig, build())
+        module.__dict__["_derived_" + key] = hit
+    return hit[1]
+
+
+def _tokens(x):
+    """channels_last [B, C, h, w] -> token-major [B, h*w, C] (a view: the two layouts are the same bytes)"""
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(b, h * w, c)
+
+
+def _image(t, h, w):
+    """token-major [B, h*w, C] -> channels_last [B, C, h, w] (a view)"""
+    b, _, c = t.shape
+    return t.reshape(b, h, w, c).permute(0, 3, 1, 2)
+
+
 class Conv1x1(nn.Conv2d):
-    """1x1 convolution run as a GEMM over channels (hipBLASLt) instead of a MIOpen convolution: same parameters and
-    state_dict keys as nn.Conv2d(cin, cout, 1).  MIOpen's 1x1 kernels at small spatial sizes accumulate with atomics
-    (measured: run-to-run differences of 3e-2 at 128->64 @ 2x2), the GEMM is bit-reproducible."""
+    """1x1 convolution run as a token-major GEMM (hipBLASLt) instead of a MIOpen convolution: same parameters and
+    state_dict keys as nn.Conv2d(cin, cout, 1).  With channels-last activations the [B, h*w, C] token view is free,
+    and MIOpen's 1x1 kernels at small spatial sizes accumulate with atomics (measured: run-to-run differences of 3e-2
+    at 128->64 @ 2x2) while the GEMM is bit-reproducible."""
 
     def __init__(self, cin, cout):
         super().__init__(cin, cout, 1)
 
+    def tokens(self, t, bias=None):
+        return F.linear(t, self.weight.flatten(1), self.bias if bias is None else bias)
+
     def forward(self, x, residual=None):
         b, c, h, w = x.shape
-        w2 = self.weight.view(self.out_channels, c)
-        y = torch.matmul(w2, x.reshape(b, c, h * w))
-        y = y + self.bias.view(1, -1, 1)
-        y = y.view(b, self.out_channels, h, w)
-        return y if residual is None else y + residual
-
-    def tokens(self, x):
-        """[B, C, h, w] -> projected tokens [B, h*w, Cout] without an NCHW->NLC copy"""
-        b, c, h, w = x.shape
-        return F.linear(x.reshape(b, c, h * w).transpose(1, 2), self.weight.view(self.out_channels, c), self.bias)
-
-    def from_tokens(self, t, h, w, residual):
-        """tokens [B, L, C] -> [B, Cout, h, w] (+ residual)"""
-        b, L, c = t.shape
-        y = torch.matmul(self.weight.view(self.out_channels, c), t.transpose(1, 2)) + self.bias.view(1, -1, 1)
-        return y.view(b, self.out_channels, h, w) + residual
+        y = self.tokens(_tokens(x))
+        if residual is not None:
+            y = y + _tokens(residual)
+        return _image(y, h, w)
 
 
 class GroupNormAct(nn.GroupNorm):
-    """GroupNorm optionally fused with SiLU (HIP kernel on the GPU)."""
+    """GroupNorm optionally fused with SiLU and with a per-(b, c) additive term (HIP kernel, channels-last)."""
 
     def __init__(self, groups, channels, eps, act=False):
         super().__init__(groups, channels, eps=eps, affine=True)
         self.act = act
 
-    def forward(self, x):
-        return ops.groupnorm_silu(x, self.num_groups, self.weight, self.bias, self.eps, self.act)
+    def forward(self, x, add=None):
+        return ops.groupnorm_silu_nhwc(x, self.num_groups, self.weight, self.bias, self.eps, self.act, add=add)
 
 
 class Attention(nn.Module):
@@ -136,6 +155,14 @@ class Attention(nn.Module):
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(0.0)])
         self.processor = AttnProcessor2_0()
         self._proc_params = None
+        # set by the pipeline for cross-attention: {"src": text tensor, "k": to_k(text), "v": to_v(text)} - the text
+        # does not change during a generation, so its projections are computed once, not once per step
+        self.kv_cache = None
+
+    def qkv_weight(self):
+        """[3C, C] concatenation of to_q / to_k / to_v for self-attention: one GEMM instead of three"""
+        return _derived(self, "qkv", (self.to_q.weight, self.to_k.weight, self.to_v.weight),
+                        lambda: torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight]).contiguous())
 
     def set_processor(self, processor):
         # a Module processor (AttnProcessor) registers as a child; drop that entry before a plain object replaces it
@@ -223,17 +250,12 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, encoder_hidden_states, cross_attention_kwargs):
         b, c, h, w = x.shape
-        res = x
-        x = self.norm(x)
-        if self.use_linear_projection:
-            x = self.proj_in(x.permute(0, 2, 3, 1).reshape(b, h * w, c))
-        else:
-            x = self.proj_in.tokens(x)
+        t = _tokens(self.norm(x))                               # channels-last: the token view is free
+        t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
         for blk in self.transformer_blocks:
-            x = blk(x, encoder_hidden_states, cross_attention_kwargs)
-        if self.use_linear_projection:
-            return self.proj_out(x).reshape(b, h, w, c).permute(0, 3, 1, 2) + res
-        return self.proj_out.from_tokens(x, h, w, res)
+            t = blk(t, encoder_hidden_states, cross_attention_kwargs)
+        t = self.proj_out(t) if self.use_linear_projection else self.proj_out.tokens(t)
+        return _image(t + _tokens(x), h, w)
 
 
 class ResnetBlock2D(nn.Module):
@@ -246,11 +268,24 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
         self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
 
-    def forward(self, x, temb_act):
-        h = self.conv1(self.norm1(x))
-        h = h + self.time_emb_proj(temb_act)[:, :, None, None]
-        h = self.conv2(self.norm2(h))
-        return self.conv_shortcut(x, residual=h) if self.conv_shortcut is not None else x + h
+    def temb_bias(self):
+        """time_emb_proj.bias + conv1.bias: conv1 runs WITHOUT its bias and the sum rides in norm2's fused add"""
+        return _derived(self, "tb", (self.time_emb_proj.bias, self.conv1.bias),
+                        lambda: (self.time_emb_proj.bias + self.conv1.bias).contiguous())
+
+    def forward(self, x, temb_act, temb_add=None):
+        # conv biases never run as separate MIOpen bias kernels: conv1's is folded into the time-embedding term (which
+        # is itself folded into norm2's load), conv2's into the shortcut GEMM's bias or the fused residual add
+        h = F.conv2d(self.norm1(x), self.conv1.weight, None, padding=1)
+        if temb_add is None:
+            temb_add = F.linear(temb_act, self.time_emb_proj.weight, self.temb_bias())
+        h = F.conv2d(self.norm2(h, add=temb_add), self.conv2.weight, None, padding=1)
+        if self.conv_shortcut is None:
+            return ops.add_bias_residual(x, h, self.conv2.bias)
+        b = _derived(self, "sb", (self.conv_shortcut.bias, self.conv2.bias),
+                     lambda: (self.conv_shortcut.bias + self.conv2.bias).contiguous())
+        bsz, _, hh, ww = h.shape
+        return _image(self.conv_shortcut.tokens(_tokens(x), bias=b) + _tokens(h), hh, ww)
 
 
 class Downsample2D(nn.Module):
@@ -351,8 +386,33 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
             self.up_blocks.append(_Block(io, td, cfg, rev_heads[i], rev_depth[i], up=i < n - 1))
             prev = c
         assert not skip
+        self._channels_last = False
         self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[0], cfg.norm_eps, act=True)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
+
+    def _resnets(self):
+        out = []
+        for blk in self.down_blocks:
+            out += list(blk.resnets)
+        out += list(self.mid_block.resnets)
+        for blk in self.up_blocks:
+            out += list(blk.resnets)
+        return out
+
+    def _all_temb_adds(self, temb_act):
+        """the 22 per-ResNet `time_emb_proj(silu(temb))` GEMMs ([B,1280] x [cout,1280]) as ONE GEMM over the
+        concatenated weights; returns {resnet: [B, cout] view}.  Offsets are multiples of 8 (16-byte aligned rows)."""
+        res = self._resnets()
+        deps = tuple(p for r in res for p in (r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias))
+        W, Bv = _derived(self, "temb", deps, lambda: (torch.cat([r.time_emb_proj.weight for r in res]).contiguous(),
+                                                       torch.cat([r.time_emb_proj.bias + r.conv1.bias for r in res])))
+        allp = F.linear(temb_act, W, Bv)
+        out, off = {}, 0
+        for r in res:
+            n = r.time_emb_proj.out_features
+            out[r] = allp[:, off:off + n]
+            off += n
+        return out
 
     # ---- processor plumbing (reference :689-749)
     @property
@@ -398,11 +458,19 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
         timestep = timestep.reshape(-1).expand(sample.shape[0])
         emb = self.time_embedding(self.time_proj(timestep, self.cfg.block_out_channels[0]).to(sample.dtype))
         temb_act = F.silu(emb)                                   # every ResnetBlock applies SiLU to temb first
-        x = self.conv_in(sample)
+        if not self._channels_last:                              # conv weights to NHWC once: no per-call transposes
+            self.to(memory_format=torch.channels_last)
+            # MIOpen has no NHWC implicit-GEMM for 4 channels (it falls back to a 300-400 us naive kernel):
+            # the two 4-channel convolutions run NCHW and convert at the boundary (a 2.6 MB copy each)
+            for conv in (self.conv_in, self.conv_out):
+                conv.weight.data = conv.weight.data.contiguous()
+            self._channels_last = True
+        x = self.conv_in(sample.contiguous()).contiguous(memory_format=torch.channels_last)
+        tadd = self._all_temb_adds(temb_act)
         skips = [x]
         for blk in self.down_blocks:
             for j, res in enumerate(blk.resnets):
-                x = res(x, temb_act)
+                x = res(x, temb_act, tadd[res])
                 if blk.has_attn:
                     x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
                 skips.append(x)
@@ -411,18 +479,18 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
                 skips.append(x)
         if down_block_additional_residuals is not None:          # ControlNet hook (reference :1236-1245)
             skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
-        x = self.mid_block.resnets[0](x, temb_act)
+        x = self.mid_block.resnets[0](x, temb_act, tadd[self.mid_block.resnets[0]])
         for attn in self.mid_block.attentions:
             x = attn(x, encoder_hidden_states, cross_attention_kwargs)
-        x = self.mid_block.resnets[1](x, temb_act)
+        x = self.mid_block.resnets[1](x, temb_act, tadd[self.mid_block.resnets[1]])
         if mid_block_additional_residual is not None:            # reference :1269-1270
             x = x + mid_block_additional_residual
         for blk in self.up_blocks:
             for j, res in enumerate(blk.resnets):
-                x = res(torch.cat([x, skips.pop()], dim=1), temb_act)
+                x = res(torch.cat([x, skips.pop()], dim=1), temb_act, tadd[res])
                 if blk.has_attn:
                     x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
             if hasattr(blk, "upsamplers"):
                 x = blk.upsamplers[0](x)
-        x = self.conv_out(self.conv_norm_out(x))                 # reference :1304-1307
+        x = self.conv_out(self.conv_norm_out(x).contiguous()).contiguous()   # reference :1304-1307; NCHW out
         return UNet2DConditionOutput(sample=x) if return_dict else (x,)

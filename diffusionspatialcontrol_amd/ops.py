@@ -146,6 +146,57 @@ def groupnorm_silu(x, groups, weight, bias, eps, act):
     return y
 
 
+def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
+    """GroupNorm(groups, eps) [+ SiLU] over channels-last fp16 (dsc_groupnorm_silu_nhwc).
+
+    x: a channels_last [B, C, h, w] tensor (returned likewise) or token-major [B, hw, C].  add: optional [B, C] added
+    to x first (the ResNet block's time-embedding term)."""
+    _require_gpu(x)
+    lib = _lib.load_library()
+    if x.dtype != torch.float16:
+        raise TypeError("groupnorm_silu_nhwc: fp16 only")
+    if x.dim() == 4:
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        B, C, h, w = x.shape
+        hw = h * w
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+    else:
+        x = x.contiguous()
+        B, hw, C = x.shape
+        y = torch.empty_like(x)
+    add_stride = 0
+    if add is not None:
+        if add.stride(-1) != 1 or add.stride(0) % 8 != 0 or add.data_ptr() % 16 != 0:
+            add = add.contiguous()
+        add_stride = add.stride(0)
+    ws = _workspace(x.device, lib.dsc_groupnorm_nhwc_workspace_bytes(B, C, hw, groups))
+    rc = lib.dsc_groupnorm_silu_nhwc(_p(x), _p(y), _p(weight), _p(bias), _p(add), add_stride, B, C, hw, groups, float(eps),
+                                     1 if act else 0, 0, _p(ws), ws.numel() * 8, _stream_ptr(x))
+    _lib.check(rc, "dsc_groupnorm_silu_nhwc")
+    return y
+
+
+def add_bias_residual(a, b, bias=None):
+    """a + b + bias[c] over channels-last / token-major fp16 tensors of identical layout (dsc_add_bias_residual)."""
+    _require_gpu(a, b)
+    if a.dim() == 4:
+        cl = torch.channels_last
+        if not a.is_contiguous(memory_format=cl):
+            a = a.contiguous(memory_format=cl)
+        if not b.is_contiguous(memory_format=cl):
+            b = b.contiguous(memory_format=cl)
+        C = a.shape[1]
+        out = torch.empty_like(a, memory_format=cl)
+    else:
+        a, b = a.contiguous(), b.contiguous()
+        C = a.shape[-1]
+        out = torch.empty_like(a)
+    rc = _lib.load_library().dsc_add_bias_residual(_p(a), _p(b), _p(bias), _p(out), a.numel() // C, C, 0, _stream_ptr(a))
+    _lib.check(rc, "dsc_add_bias_residual")
+    return out
+
+
 def geglu(x):
     """hidden * gelu(gate) for x = [..., 2n] fp16 contiguous (dsc_geglu)."""
     _require_gpu(x)

@@ -129,6 +129,26 @@ int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, const void* be
                        int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/*
+ * GroupNorm (+ optional SiLU) over channels-last (NHWC) fp16 - the layout the UNet keeps its activations in so that
+ * MIOpen's NHWC implicit-GEMM convolutions and the transformer's token-major GEMMs need no transposes.
+ *   x, y  : [B, hw, C] (= a channels_last [B, C, h, w] tensor), C % 8 == 0, C/8 <= 512
+ *   add   : optional fp16 [B, C] added to x before the statistics and the normalisation - fuses the ResNet block's
+ *           `hidden + time_emb_proj(silu(temb))[:, :, None, None]` (diffusers ResnetBlock2D) into the norm that follows
+ *   y[b,p,c] = act(((x[b,p,c] + add[b,c]) - mean_bg) * rstd_bg * gamma[c] + beta[c])
+ * Every access is a coalesced 16-byte vector; two launches (per-chunk partial sums, apply); bit-reproducible.
+ */
+size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int groups);
+int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta,
+                            const void* add, int64_t add_row_stride,   /* elements between rows of `add` (>= C) */
+                            int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* out[r, c] = a[r, c] + b[r, c] + bias[c] over fp16 [rows, C] (channels-last residual add with the convolution's
+ * bias folded in: the ResNet block's `x + conv2(h)` where conv2 ran without its bias).  bias may be NULL. C % 8 == 0. */
+int dsc_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t rows, int C,
+                          int dtype, void* stream);
+
 /* GEGLU of the transformer feed-forward (diffusers GEGLU): y[r, j] = x[r, j] * gelu(x[r, n + j]), exact erf gelu.
  * x fp16 [rows, 2n] contiguous, y fp16 [rows, n]; n % 8 == 0. */
 int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);
