@@ -16,8 +16,11 @@
 //   O^T[dd, l] = sum_s V^T[dd, s] P^T[s, l]: the fp16-packed score registers are already the B operand of this
 //   MFMA (k order permuted inside each 16-step); the A operand V^T is read from an LDS image transposed at
 //   staging time in exactly that permuted order.
-// K (zero-padded to 96 x 16*NK) and V^T are staged once per workgroup in LDS and shared by its 4 waves; the
-// fp32 region tile of a wave (32 rows x S, contiguous in HBM) is staged through LDS with coalesced loads.
+// K (pad columns zeroed) and V (row-major; the V^T operand is read with ds_read_b64_tr_b16, the hardware transpose)
+// are staged once per workgroup in LDS and shared by its 4 waves; the fp32 region tile of a wave (32 rows x S,
+// contiguous in HBM) is staged through LDS with coalesced 16-byte loads.  ALL global loads of the prologue (K, V,
+// Q fragments, region tile, std partials) are issued up front into registers with compile-time trip counts, so the
+// workgroup pays ONE memory round trip before its first MFMA instead of one per staging-loop iteration.
 // blockIdx is mapped so that the H heads of one (b, row chunk) share an XCD: they re-read the same region
 // rows and the same 128-B lines of Q from that XCD's L2.
 #include "dsc_common.h"
@@ -26,7 +29,7 @@
 namespace {
 
 constexpr int kSMax = 96;        // key length padded to 3 MFMA row tiles
-constexpr int kSP = 100;         // V^T LDS row stride in halves: 50 dwords -> ds_read_b64 conflict-free over 32 rows
+typedef short s4_t __attribute__((__vector_size__(4 * sizeof(short))));
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 
@@ -58,36 +61,65 @@ __device__ __forceinline__ void block_to_work(const XattnParams& p, int& b, int&
     chunk = cg % p.nchunks;
 }
 
-// K[b, :, h, :] -> LDS image Ks[96][KP], zero outside s < S, col < d.
 template <int NK>
-__device__ __forceinline__ void stage_k(const XattnParams& p, half_t* Ks, int b, int h) {
-    constexpr int KP = 16 * NK + 8, KP8 = KP / 8;
+struct XCfg {
+    static constexpr int DM = (NK + 1) / 2;
+    static constexpr int KP = 16 * NK + 8;                  // K row stride (halves): odd multiple of 16 B
+    static constexpr int VP = (DM <= 3) ? 96 : 160;         // V row stride: tr reads conflict-free ((VP/2) % 64 in {16,48})
+    static constexpr int CH = (kSMax * 2 * NK + kThreads - 1) / kThreads;   // 16-B chunks per thread per operand
+};
+
+__device__ __forceinline__ h4_t tr_read(const half_t* p) {
+    const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s4_t __attribute__((address_space(3)))*)(const_cast<half_t*>(p)));
+    return __builtin_bit_cast(h4_t, r);
+}
+
+// K[b, :, h, :] (and V) -> registers: chunk idx = s * d8 + c covers 8 halves; all loads issued back to back
+template <int NK, bool WITH_V>
+__device__ __forceinline__ void kv_load(const XattnParams& p, int b, int h, h8_t (&kr)[XCfg<NK>::CH], h8_t (&vr)[XCfg<NK>::CH]) {
     const half_t* kb = p.k + b * p.ksb + h * p.ksh;
-    for (int idx = threadIdx.x; idx < kSMax * KP8; idx += kThreads) {
-        const int s = idx / KP8, c = idx - s * KP8;
-        h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (s < p.S && c * 8 < p.d) val = *reinterpret_cast<const h8_t*>(kb + s * p.kss + c * 8);
-        *reinterpret_cast<h8_t*>(Ks + s * KP + c * 8) = val;
+    const half_t* vb = p.v + b * p.vsb + h * p.vsh;
+    const int d8 = p.d >> 3, n = p.S * d8;
+#pragma unroll
+    for (int c = 0; c < XCfg<NK>::CH; ++c) {
+        const int idx = threadIdx.x + c * kThreads;
+        if (idx < n) {
+            const int s = idx / d8, col = idx - s * d8;
+            kr[c] = *reinterpret_cast<const h8_t*>(kb + s * p.kss + col * 8);
+            if (WITH_V) vr[c] = *reinterpret_cast<const h8_t*>(vb + s * p.vss + col * 8);
+        }
     }
 }
 
-// V[b, :, h, :] -> LDS image Vt[32*DM][kSP] (transposed), zero outside dd < d, s < S.
-template <int DM>
-__device__ __forceinline__ void stage_vt(const XattnParams& p, half_t* Vt, int b, int h) {
-    const half_t* vb = p.v + b * p.vsb + h * p.vsh;
-    const int d8 = p.d >> 3;
-    for (int idx = threadIdx.x; idx < p.S * d8; idx += kThreads) {
-        const int s = idx / d8, c = idx - s * d8;
-        const h8_t val = *reinterpret_cast<const h8_t*>(vb + s * p.vss + c * 8);
+// registers -> LDS images Ks[96][KP] / Vs[96][VP] (row-major), plus the few zeros the MFMAs need:
+//   K columns [d, 16*NK): the Q fragment is zero there, but 0 * (NaN garbage) would poison the score;
+//   V rows [S, 16*ceil(S/16)): P is exactly 0 there, same reason.  K rows >= S only feed scores that are replaced by
+//   -inf (a select, not arithmetic) and V columns >= d only feed output rows that are never stored: left as they are.
+template <int NK, bool WITH_V>
+__device__ __forceinline__ void kv_store(const XattnParams& p, half_t* Ks, half_t* Vs, const h8_t (&kr)[XCfg<NK>::CH],
+                                         const h8_t (&vr)[XCfg<NK>::CH]) {
+    constexpr int KP = XCfg<NK>::KP, VP = XCfg<NK>::VP;
+    const int d8 = p.d >> 3, n = p.S * d8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Vt[(c * 8 + j) * kSP + s] = val[j];
+    for (int c = 0; c < XCfg<NK>::CH; ++c) {
+        const int idx = threadIdx.x + c * kThreads;
+        if (idx < n) {
+            const int s = idx / d8, col = idx - s * d8;
+            *reinterpret_cast<h8_t*>(Ks + s * KP + col * 8) = kr[c];
+            if (WITH_V) *reinterpret_cast<h8_t*>(Vs + s * VP + col * 8) = vr[c];
+        }
     }
-    const int padrows = 32 * DM - p.d;                       // rows dd >= d
-    for (int idx = threadIdx.x; idx < padrows * kSP; idx += kThreads) Vt[p.d * kSP + idx] = (half_t)0;
-    const int padcols = kSP - p.S;                           // cols s >= S of the live rows
-    for (int idx = threadIdx.x; idx < p.d * padcols; idx += kThreads) {
-        const int dd = idx / padcols, s = p.S + (idx - dd * padcols);
-        Vt[dd * kSP + s] = (half_t)0;
+    const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const int padc = 2 * NK - d8;                        // 16-byte pad chunks per row (0 when d == 16*NK)
+        for (int idx = threadIdx.x; idx < kSMax * padc; idx += kThreads)
+            *reinterpret_cast<h8_t*>(Ks + (idx / padc) * KP + p.d + (idx % padc) * 8) = z;
+    }
+    if (WITH_V) {
+        const int zrows = ((p.S + 15) & ~15) - p.S, v8 = VP / 8;
+        for (int idx = threadIdx.x; idx < zrows * v8; idx += kThreads)
+            *reinterpret_cast<h8_t*>(Vs + (p.S + idx / v8) * VP + (idx % v8) * 8) = z;
     }
 }
 
@@ -107,7 +139,7 @@ __device__ __forceinline__ void load_q_frags(const XattnParams& p, h8_t (&qf)[NK
 template <int NK, bool REF16>
 __device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, const h8_t (&qf)[NK], f16x_t (&acc)[3],
                                        int r, int hh, float scale) {
-    constexpr int KP = 16 * NK + 8;
+    constexpr int KP = XCfg<NK>::KP;
     const int mt = (p.S + 31) >> 5;
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -133,13 +165,20 @@ __device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, c
 template <int NK, bool REF16>
 __global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KP = 16 * NK + 8;
+    constexpr int KP = XCfg<NK>::KP;
     half_t* Ks = reinterpret_cast<half_t*>(smem);
     double* red = reinterpret_cast<double*>(smem + kSMax * KP * 2);
     int b, h, chunk;
     block_to_work(p, b, h, chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    stage_k<NK>(p, Ks, b, h);
+    h8_t kr[XCfg<NK>::CH], vr[XCfg<NK>::CH];
+    kv_load<NK, false>(p, b, h, kr, vr);
+    h8_t qf[NK];
+    {   // first tile's Q fragments ride the same round trip as K
+        const int l0f = (chunk * kWaves * p.tiles_per_wave + wave) * 32;
+        load_q_frags<NK>(p, qf, b, h, min(l0f + r, p.L - 1), hh);
+    }
+    kv_store<NK, false>(p, Ks, nullptr, kr, vr);
     __syncthreads();
     float s1 = 0.f, s2 = 0.f;
     double d1 = 0.0, d2 = 0.0;
@@ -148,8 +187,7 @@ __global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
         if (l0 >= p.L) break;
         const int row = min(l0 + r, p.L - 1);
         const bool row_ok = l0 + r < p.L;
-        h8_t qf[NK];
-        load_q_frags<NK>(p, qf, b, h, row, hh);
+        if (t > 0) load_q_frags<NK>(p, qf, b, h, row, hh);
         f16x_t acc[3];
         scores<NK, REF16>(p, Ks, qf, acc, r, hh, p.scale);
 #pragma unroll
@@ -178,12 +216,15 @@ __global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
     }
 }
 
-// group std from the partials: every thread of the block gets the same value (fixed summation order)
-__device__ __forceinline__ float group_std(const XattnParams& p, int g, double* red, bool ref16) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// group std from the partials: every thread of the block gets the same value (fixed summation order).
+// Split in two so that the partial loads are in flight together with the K / V / Q loads of the prologue.
+__device__ __forceinline__ void group_partials(const XattnParams& p, int g, double& a1, double& a2) {
     const double* src = p.partials + (long long)g * p.npart * 2;
-    double a1 = 0.0, a2 = 0.0;
+    a1 = 0.0; a2 = 0.0;
     for (int i = threadIdx.x; i < p.npart; i += kThreads) { a1 += src[2 * i]; a2 += src[2 * i + 1]; }
+}
+__device__ __forceinline__ float group_std_finish(const XattnParams& p, double a1, double a2, double* red, bool ref16) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     a1 = wave_sum_f64(a1);
     a2 = wave_sum_f64(a2);
     if (lane == 0) { red[2 * wave] = a1; red[2 * wave + 1] = a2; }
@@ -197,6 +238,11 @@ __device__ __forceinline__ float group_std(const XattnParams& p, int g, double* 
     if (ref16) sd = round_f16(sd);                           // std of an fp16 tensor is a 0-dim fp16 tensor
     return sd;
 }
+__device__ __forceinline__ float group_std(const XattnParams& p, int g, double* red, bool ref16) {
+    double a1, a2;
+    group_partials(p, g, a1, a2);
+    return group_std_finish(p, a1, a2, red, ref16);
+}
 
 // finalises std_out[g] for dsc_region_xattn_std (one block per group)
 template <bool REF16>
@@ -207,52 +253,94 @@ __global__ __launch_bounds__(kThreads) void xattn_std_finalize(XattnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ phase 2
+constexpr int kWCH = (32 * kSMax / 4 + 63) / 64;             // float4 chunks per lane of one 32 x S region tile (12)
+
 template <int NK, bool REF16>
 __global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KP = 16 * NK + 8, DM = (NK + 1) / 2;
+    using C = XCfg<NK>;
+    constexpr int KP = C::KP, VP = C::VP, DM = C::DM;
     half_t* Ks = reinterpret_cast<half_t*>(smem);
-    half_t* Vt = Ks + kSMax * KP;
-    double* red = reinterpret_cast<double*>(Vt + 32 * DM * kSP);
+    half_t* Vs = Ks + kSMax * KP;
+    double* red = reinterpret_cast<double*>(Vs + kSMax * VP);
     float* Wt_all = reinterpret_cast<float*>(red + 2 * kWaves);
     int b, h, chunk;
     block_to_work(p, b, h, chunk);
+    if (p.flags & 8u) return;                                // DEBUG timing probe: launch floor
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
     const bool has_bias = p.region != nullptr;
-    const bool bias_final = (p.flags & DSC_FLAG_BIAS_IS_FINAL) != 0;
+    const bool need_std = has_bias && !(p.flags & DSC_FLAG_BIAS_IS_FINAL);
     const int wt_stride = (32 * p.S + 3) & ~3;
     float* Wt = Wt_all + wave * wt_stride;
-
-    stage_k<NK>(p, Ks, b, h);
-    stage_vt<DM>(p, Vt, b, h);
-    float sig = 1.f, sd = 1.f;
-    if (has_bias && !bias_final) {
-        sd = group_std(p, b % p.n_groups, red, REF16);       // contains a __syncthreads()
-        sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
-    }
     const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;   // repeat_interleave, :96-99
     const int mt = (p.S + 31) >> 5, nt = (p.S + 15) >> 4;
 
-    for (int t = 0; t < p.tiles_per_wave; ++t) {
-        const int l0 = (chunk * kWaves * p.tiles_per_wave + t * kWaves + wave) * 32;
-        const bool tile_ok = l0 < p.L;                       // wave-uniform
-        const int nrows = tile_ok ? min(32, p.L - l0) : 0;
-        const int row = tile_ok ? min(l0 + r, p.L - 1) : 0;
-        h8_t qf[NK];
-        if (tile_ok) {
-            load_q_frags<NK>(p, qf, b, h, row, hh);
-            if (has_bias) {                                  // fp32 region rows l0 .. l0+nrows-1: contiguous
-                const float* src = p.region + ((long long)bw * p.L + l0) * p.S;
-                const int cnt = nrows * p.S;
-                if (((((long long)bw * p.L + l0) * p.S) & 3) == 0 && (cnt & 3) == 0) {
-                    for (int i = lane * 4; i < cnt; i += 256)
-                        *reinterpret_cast<f4x_t*>(Wt + i) = *reinterpret_cast<const f4x_t*>(src + i);
-                } else {
-                    for (int i = lane; i < cnt; i += 64) Wt[i] = src[i];
+    // ---- prologue: every global load of the workgroup is issued before anything waits
+    h8_t kr[C::CH], vr[C::CH];
+    kv_load<NK, true>(p, b, h, kr, vr);
+    double pa1 = 0.0, pa2 = 0.0;
+    if (need_std) group_partials(p, b % p.n_groups, pa1, pa2);
+    float sig = 1.f;
+    if (need_std) sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
+
+    h8_t qf[NK];
+    f4x_t wreg[kWCH];
+    auto tile_loads = [&](int l0, int nrows, int row, bool& vec) {
+        load_q_frags<NK>(p, qf, b, h, row, hh);
+        vec = false;
+        if (has_bias) {                                      // fp32 region rows l0 .. l0+nrows-1 are contiguous
+            const long long off = ((long long)bw * p.L + l0) * p.S;
+            const int cnt = nrows * p.S;
+            vec = ((off & 3) == 0) && ((cnt & 3) == 0);
+            if (vec) {
+                const f4x_t* src = reinterpret_cast<const f4x_t*>(p.region + off);
+#pragma unroll
+                for (int c = 0; c < kWCH; ++c) {
+                    const int i = lane + 64 * c;
+                    if (i * 4 < cnt) wreg[c] = src[i];
                 }
             }
         }
-        __syncthreads();          // t == 0: K / V^T images complete; every t: this wave's Wt tile is written
+    };
+    auto tile_store_w = [&](int l0, int nrows, bool vec) {
+        if (!has_bias) return;
+        const int cnt = nrows * p.S;
+        if (vec) {
+#pragma unroll
+            for (int c = 0; c < kWCH; ++c) {
+                const int i = lane + 64 * c;
+                if (i * 4 < cnt) *reinterpret_cast<f4x_t*>(Wt + 4 * i) = wreg[c];
+            }
+        } else {                                             // odd alignment / ragged tail: plain dword loop
+            const float* src = p.region + ((long long)bw * p.L + l0) * p.S;
+            for (int i = lane; i < cnt; i += 64) Wt[i] = src[i];
+        }
+    };
+
+    int l0 = (chunk * kWaves * p.tiles_per_wave + wave) * 32;
+    bool tile_ok = l0 < p.L, vec = false;
+    int nrows = tile_ok ? min(32, p.L - l0) : 0;
+    int row = tile_ok ? min(l0 + r, p.L - 1) : 0;
+    if (tile_ok) tile_loads(l0, nrows, row, vec);
+
+    kv_store<NK, true>(p, Ks, Vs, kr, vr);
+    float sd = 1.f;
+    if (need_std) sd = group_std_finish(p, pa1, pa2, red, REF16);          // contains a __syncthreads()
+    if (tile_ok) tile_store_w(l0, nrows, vec);
+
+    // transposed-read lane offset: row 4 hh + ((lane & 15) >> 2), column 16 ((lane >> 4) & 1) + 4 (lane & 3)
+    const int tr_off = (4 * hh + ((lane & 15) >> 2)) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    for (int t = 0; t < p.tiles_per_wave; ++t) {
+        if (t > 0) {
+            l0 = (chunk * kWaves * p.tiles_per_wave + t * kWaves + wave) * 32;
+            tile_ok = l0 < p.L;
+            nrows = tile_ok ? min(32, p.L - l0) : 0;
+            row = tile_ok ? min(l0 + r, p.L - 1) : 0;
+            if (tile_ok) { tile_loads(l0, nrows, row, vec); tile_store_w(l0, nrows, vec); }
+        }
+        __syncthreads();          // t == 0: K / V images complete; every t: this wave's Wt tile is written
+        if (p.flags & 16u) return;                           // DEBUG timing probe: prologue only
         if (tile_ok) {
             f16x_t acc[3];
             scores<NK, REF16>(p, Ks, qf, acc, r, hh, p.scale);
@@ -298,16 +386,16 @@ __global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
             const bool row_ok = l0 + r < p.L;
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm) {
-                if (32 * dm < p.d) {
+                if (32 * dm < p.d) {                         // wave-uniform: EXEC stays full for the transposed reads
                     f16x_t o;
 #pragma unroll
                     for (int i = 0; i < 16; ++i) o[i] = 0.f;
-                    const half_t* vrow = Vt + (32 * dm + r) * kSP + 4 * hh;
 #pragma unroll
                     for (int tt = 0; tt < 6; ++tt) {
                         if (tt < nt) {
-                            const h4_t lo = *reinterpret_cast<const h4_t*>(vrow + 16 * tt);
-                            const h4_t hi = *reinterpret_cast<const h4_t*>(vrow + 16 * tt + 8);
+                            const half_t* vp = Vs + tr_off + (16 * tt) * VP + 32 * dm;
+                            const h4_t lo = tr_read(vp);
+                            const h4_t hi = tr_read(vp + 8 * VP);
                             const h8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             o = mfma_32x32x16(vf, pf[tt], o);
                         }
@@ -330,14 +418,13 @@ __global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
 
 template <int NK>
 size_t fwd_lds_bytes(int S) {
-    constexpr int KP = 16 * NK + 8, DM = (NK + 1) / 2;
     const int wt_stride = (32 * S + 3) & ~3;
-    return (size_t)kSMax * KP * 2 + (size_t)32 * DM * kSP * 2 + 2 * kWaves * 8 + (size_t)kWaves * wt_stride * 4;
+    return (size_t)kSMax * XCfg<NK>::KP * 2 + (size_t)kSMax * XCfg<NK>::VP * 2 + 2 * kWaves * 8 +
+           (size_t)kWaves * wt_stride * 4;
 }
 template <int NK>
 size_t stats_lds_bytes() {
-    constexpr int KP = 16 * NK + 8;
-    return (size_t)kSMax * KP * 2 + 2 * kWaves * 8;
+    return (size_t)kSMax * XCfg<NK>::KP * 2 + 2 * kWaves * 8;
 }
 
 int pick_nk(int d) {

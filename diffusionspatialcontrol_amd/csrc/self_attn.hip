@@ -1,0 +1,280 @@
+// Flash self-attention forward for gfx950 (MI355X): the kernel behind dsc_self_attn_fwd.
+//
+// Replaces `F.scaled_dot_product_attention(query, key, value)` on the self-attention branch of the processors
+// (source/modules/attention_modify.py:483-485) for the UNet's head dims 40 / 64 / 80 / 160.
+// The L x L score matrix is never materialised: per 32-query-row wave, KV tiles of 64 keys stream through LDS with an
+// online softmax (running max m, running sum l per query row).
+//
+// MI355X mapping (64-wide waves, MFMA 32x32x16 f16):
+//   * S^T[kv, q] = K[kv, :] . Q[q, :]  ("swapped" product: A = K rows from LDS, B = Q^T kept in registers for the whole
+//     kernel) puts ONE query row on each lane (q = lane & 31) with half of the tile's 64 scores in its registers, so
+//     max / exp2 / sum are lane-local plus one exchange with lane ^ 32;
+//   * O^T[d, q] += V^T[d, kv] . P^T[kv, q]: the fp16-packed probabilities are already the B operand (k order
+//     permuted inside each 16-step, cdna_hip_programming.md section 3 "accumulator tile as the next MFMA's operand"); the A
+//     operand V^T comes from the ROW-MAJOR V tile in LDS through ds_read_b64_tr_b16 (hardware transpose), two reads
+//     per MFMA, conflict-free with a row stride of 96 / 160 halves;
+//   * K / V tiles are double-buffered in LDS: the global loads of tile t+1 are issued before the MFMAs of tile t and
+//     written after them (one barrier per tile);
+//   * blockIdx is remapped so that all query blocks of one (b, h) run on one XCD: its K / V (L*d*4 bytes) is fetched
+//     from HBM once and then served by that XCD's L2.
+// Bound: MFMA (arithmetic intensity 4*L*L*C / 8*L*C = L/2 FLOP/B); head dim 40 pads to 48 (QK^T) and 64 (PV).
+#include "dsc_common.h"
+#include "dsc_hip.h"
+
+namespace {
+
+typedef short s4_t __attribute__((__vector_size__(4 * sizeof(short))));
+
+constexpr int kKV = 64;          // keys per tile
+
+struct SaParams {
+    const half_t* q; const half_t* k; const half_t* v; half_t* out;
+    int Bc, H, L, S, d;          // S = number of keys (== L for self-attention)
+    int nqb, xcd_map;
+    float scale_log2e;
+    long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
+};
+
+template <int NK>
+struct SaCfg {
+    static constexpr int DM = (NK + 1) / 2;
+    static constexpr int KP = 16 * NK + 8;                  // K row stride (halves): odd multiple of 16 B
+    static constexpr int VP = (DM <= 3) ? 96 : 160;         // V row stride: (VP/2) % 64 in {16, 48} -> tr reads conflict-free
+    static constexpr int TILE_HALVES = kKV * KP + kKV * VP; // one (K, V) buffer
+};
+
+__device__ __forceinline__ h4_t tr_read(const half_t* p) {
+    const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s4_t __attribute__((address_space(3)))*)(const_cast<half_t*>(p)));
+    return __builtin_bit_cast(h4_t, r);
+}
+
+template <int NK, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
+    using C = SaCfg<NK>;
+    constexpr int T = 64 * WAVES, DM = C::DM, KP = C::KP, VP = C::VP;
+    constexpr int CH = (kKV * 2 * NK + T - 1) / T;          // 16-byte chunks per thread per operand per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* lds = reinterpret_cast<half_t*>(smem);
+
+    int bh, qb;
+    {
+        const int bid = blockIdx.x, nbh = p.Bc * p.H;
+        if (p.xcd_map) { const int x = bid & 7, j = bid >> 3, nb8 = nbh >> 3; bh = x + 8 * (j % nb8); qb = j / nb8; }
+        else { bh = bid % nbh; qb = bid / nbh; }
+    }
+    const int b = bh / p.H, h = bh % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int q0 = (qb * WAVES + wave) * 32;
+    const int d8 = p.d >> 3;
+    const half_t* kg = p.k + b * p.ksb + h * p.ksh;
+    const half_t* vg = p.v + b * p.vsb + h * p.vsh;
+
+    // zero the K pad columns [d, 16*NK) of both buffers once (the staging never writes them)
+    if (16 * NK > p.d) {
+        const int padc = 16 * NK - p.d;
+        for (int idx = threadIdx.x; idx < 2 * kKV * padc; idx += T) {
+            const int buf = idx / (kKV * padc), rem = idx % (kKV * padc);
+            lds[buf * C::TILE_HALVES + (rem / padc) * KP + p.d + rem % padc] = (half_t)0;
+        }
+    }
+
+    // Q^T fragments stay in registers: qf[ks] = Q[q0 + r][16 ks + 8 hh .. +8]
+    h8_t qf[NK];
+    {
+        const int row = min(q0 + r, p.L - 1);
+        const half_t* qp = p.q + b * p.qsb + h * p.qsh + (long long)row * p.qsl;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            const int col = 16 * ks + 8 * hh;
+            h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (col < p.d) val = *reinterpret_cast<const h8_t*>(qp + col);
+            qf[ks] = val;
+        }
+    }
+
+    h8_t kst[CH], vst[CH];                                   // staging registers for the next tile
+    auto stage_load = [&](int tile) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int idx = threadIdx.x + c * T;
+            const int row = idx / d8, col = idx - row * d8;
+            if (idx < kKV * d8) {
+                const int kv = min(tile * kKV + row, p.S - 1);
+                kst[c] = *reinterpret_cast<const h8_t*>(kg + (long long)kv * p.kss + col * 8);
+                vst[c] = *reinterpret_cast<const h8_t*>(vg + (long long)kv * p.vss + col * 8);
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+        half_t* Kb = lds + buf * C::TILE_HALVES;
+        half_t* Vb = Kb + kKV * KP;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int idx = threadIdx.x + c * T;
+            const int row = idx / d8, col = idx - row * d8;
+            if (idx < kKV * d8) {
+                *reinterpret_cast<h8_t*>(Kb + row * KP + col * 8) = kst[c];
+                *reinterpret_cast<h8_t*>(Vb + row * VP + col * 8) = vst[c];
+            }
+        }
+    };
+
+    f16x_t o[DM];
+#pragma unroll
+    for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dm][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (p.S + kKV - 1) / kKV;
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    // per-lane constant part of the transposed-read address: row (4 hh + (i >> 2)), column 16 * ((lane >> 4) & 1) + 4 * (i & 3)
+    const int tr_off = (4 * hh + ((lane & 15) >> 2)) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage_load(t + 1);               // in flight during this tile's MFMAs
+        const half_t* Kb = lds + buf * C::TILE_HALVES;
+        const half_t* Vb = Kb + kKV * KP;
+
+        // ---- S^T = K . Q^T  (2 row tiles of 32 keys)
+        f16x_t s[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[m][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const h8_t kf = *reinterpret_cast<const h8_t*>(Kb + (32 * m + r) * KP + 16 * ks + 8 * hh);
+                s[m] = mfma_32x32x16(kf, qf[ks], s[m]);
+            }
+        }
+        // ---- online softmax (base-2): element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this tile
+        const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float a = s[m][i] * p.scale_log2e;
+                if (kv_left < kKV && 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh >= kv_left) a = -INFINITY;
+                s[m][i] = a;
+                mx = fmaxf(mx, a);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        h8_t pf[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(s[m][i] - m_new);
+                psum += e;
+                pf[2 * m + (i >> 3)][i & 7] = (half_t)e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;
+
+        // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels)
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const half_t* vp = Vb + tr_off + (16 * tt) * VP + 32 * dm;
+                const h4_t lo = tr_read(vp);
+                const h4_t hi = tr_read(vp + 8 * VP);
+                const h8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dm] = mfma_32x32x16(vf, pf[tt], o[dm]);
+            }
+        }
+        if (t + 1 < ntiles) stage_write(buf ^ 1);            // buffer buf^1 was last read in iteration t-1
+        __syncthreads();
+    }
+
+    // ---- epilogue: O / l, fp16, out[b, q, h, :]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q0 + r < p.L) {
+        half_t* op = p.out + b * p.osb + h * p.osh + (long long)(q0 + r) * p.osl;
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                if (dd0 < p.d) {
+                    const h4_t ov = {(half_t)(o[dm][4 * g4] * inv), (half_t)(o[dm][4 * g4 + 1] * inv),
+                                     (half_t)(o[dm][4 * g4 + 2] * inv), (half_t)(o[dm][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<h4_t*>(op + dd0) = ov;
+                }
+            }
+    }
+}
+
+template <int NK, int WAVES>
+int launch(const SaParams& p0, hipStream_t st) {
+    SaParams p = p0;
+    p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
+    p.xcd_map = ((p.Bc * p.H) % 8 == 0) ? 1 : 0;
+    const size_t lds = (size_t)2 * SaCfg<NK>::TILE_HALVES * sizeof(half_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((self_attn_fwd<NK, WAVES>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}
+
+template <int NK>
+int launch_nk(const SaParams& p, hipStream_t st) {
+    // enough workgroups to fill 256 CUs: 4 waves (128 query rows) per workgroup when that still gives >= 256 of them
+    const long long wg4 = (long long)p.Bc * p.H * ((p.L + 127) / 128);
+    if (wg4 >= 256) return launch<NK, 4>(p, st);
+    const long long wg2 = (long long)p.Bc * p.H * ((p.L + 63) / 64);
+    if (wg2 >= 128 || NK >= 6) return launch<NK, 2>(p, st);   // one wave alone would need 160 staging registers at d = 160
+    return launch<NK, (NK >= 6 ? 2 : 1)>(p, st);
+}
+
+bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+bool strides_ok(const int64_t s[3]) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0; }
+
+}  // namespace
+
+extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, void* out, int Bc, int H, int L, int S,
+                                 int d, const int64_t q_strides[3], const int64_t k_strides[3],
+                                 const int64_t v_strides[3], const int64_t o_strides[3], float scale, int dtype,
+                                 void* stream) {
+    if (!q || !k || !v || !out || !q_strides || !k_strides || !v_strides || !o_strides) return DSC_ERR_BAD_ARG;
+    if (Bc <= 0 || H <= 0 || L <= 0 || S <= 0 || d <= 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16 || d % 8 != 0 || d > 160) return DSC_ERR_UNSUPPORTED;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7) ||
+        !strides_ok(q_strides) || !strides_ok(k_strides) || !strides_ok(v_strides) || !strides_ok(o_strides))
+        return DSC_ERR_UNSUPPORTED;
+    SaParams p{};
+    p.q = static_cast<const half_t*>(q); p.k = static_cast<const half_t*>(k);
+    p.v = static_cast<const half_t*>(v); p.out = static_cast<half_t*>(out);
+    p.Bc = Bc; p.H = H; p.L = L; p.S = S; p.d = d;
+    p.scale_log2e = (scale > 0.f ? scale : 1.0f / sqrtf((float)d)) * 1.4426950408889634f;
+    p.qsb = q_strides[0]; p.qsl = q_strides[1]; p.qsh = q_strides[2];
+    p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
+    p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
+    p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d <= 48) return launch_nk<3>(p, st);
+    if (d <= 64) return launch_nk<4>(p, st);
+    if (d <= 80) return launch_nk<5>(p, st);
+    if (d <= 96) return launch_nk<6>(p, st);
+    if (d <= 128) return launch_nk<8>(p, st);
+    return launch_nk<10>(p, st);
+}

@@ -44,7 +44,7 @@ def _blhd_strides(t, layout):
 
 
 def region_xattn(q, k, v, region=None, sigma=1.0, *, layout="bhld", n_std_groups=1, scale=None,
-                 ref_fp16_rounding=True, bias_is_final=False, out=None, reuse_stats=False):
+                 ref_fp16_rounding=True, bias_is_final=False, out=None, reuse_stats=False, debug_flags=0):
     """softmax(scale*q.k^T + region*sigma*std) . v  on the GPU (dsc_region_xattn_fwd).
 
     layout 'bhld': q [Bc,H,L,d], k/v [Bc,H,S,d] -> out [Bc,H,L,d] (the shape of
@@ -83,7 +83,7 @@ def region_xattn(q, k, v, region=None, sigma=1.0, *, layout="bhld", n_std_groups
     else:
         sig_host = float(sigma)
     flags = (FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0) | (FLAG_BIAS_IS_FINAL if bias_is_final else 0) \
-        | (FLAG_REUSE_STATS if reuse_stats else 0)
+        | (FLAG_REUSE_STATS if reuse_stats else 0) | debug_flags
     nbytes = lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups)
     ws = _workspace(q.device, nbytes)
     rc = lib.dsc_region_xattn_fwd(
@@ -116,13 +116,24 @@ def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp1
 
 
 # ----------------------------------------------------------------------------- ops of the UNet step
-# NOTE: entries marked INTERIM run as torch-ROCm library calls until their HIP kernel lands in csrc/.
-def self_attention(q, k, v, scale=None):
-    """softmax(q.k^T * scale) . v for q/k/v [B, L, H, d] views -> [B, L, H, d] contiguous.  INTERIM: torch SDPA."""
+def self_attention(q, k, v, scale=None, out=None):
+    """softmax(q.k^T * scale) . v for q [B, L, H, d], k/v [B, S, H, d] (strided views allowed) -> [B, L, H, d]
+    contiguous (dsc_self_attn_fwd: flash attention, scores never materialised)."""
     _require_gpu(q, k, v)
-    o = torch.nn.functional.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2),
-                                                         scale=scale)
-    return o.transpose(1, 2).contiguous()
+    if q.dtype != torch.float16:
+        raise TypeError("self_attention: fp16 only")
+    qs, (B, H, L, d) = _blhd_strides(q, "blc")
+    ks, (_, _, S, _) = _blhd_strides(k, "blc")
+    vs, _ = _blhd_strides(v, "blc")
+    if out is None:
+        out = torch.empty((B, L, H, d), dtype=q.dtype, device=q.device)
+    os_, _ = _blhd_strides(out, "blc")
+    rc = _lib.load_library().dsc_self_attn_fwd(
+        ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()),
+        ctypes.c_void_p(out.data_ptr()), B, H, L, S, d, _i64x3(*qs), _i64x3(*ks), _i64x3(*vs), _i64x3(*os_),
+        float(scale) if scale else 0.0, 0, _stream_ptr(q))
+    _lib.check(rc, "dsc_self_attn_fwd")
+    return out
 
 
 def _p(t):

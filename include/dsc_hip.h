@@ -94,6 +94,21 @@ int dsc_region_xattn_std(const void* q, const void* k,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Flash self-attention forward - replaces `F.scaled_dot_product_attention(query, key, value)` on the self-attention
+ * branch of the processors (modules/attention_modify.py:483-485) and `attn.get_attention_scores` + bmm (:187-188).
+ *   out[b,l,h,:] = softmax_s(scale * q[b,l,h,:].k[b,s,h,:]) . v[b,s,h,:]     (no mask, no dropout)
+ * Same addressing as dsc_region_xattn_fwd: q/out [Bc, L, H, d] and k/v [Bc, S, H, d] through {sb, sl|ss, sh} element
+ * strides, so the three operands can be strided views of ONE fused [Bc, L, 3*H*d] QKV projection.  The L x S scores
+ * are never written to memory (online softmax over 64-key tiles).  fp16, d % 8 == 0, d <= 160, strides % 8 == 0.
+ * scale <= 0 means 1/sqrt(d).  No workspace.
+ */
+int dsc_self_attn_fwd(const void* q, const void* k, const void* v, void* out,
+                      int Bc, int H, int L, int S, int d,
+                      const int64_t q_strides[3], const int64_t k_strides[3],
+                      const int64_t v_strides[3], const int64_t o_strides[3],
+                      float scale, int dtype, void* stream);
+
+/*
  * Fused sampler step for the k-diffusion DPM++ 2M loop with classifier-free guidance - replaces, per step,
  * `torch.cat([x]*2)` + `input * c_in` (model_k_diffusion.py:1097, external_k_diffusion.py:111),
  * `input + eps * c_out` (:114), the CFG combine (model_k_diffusion.py:1162-1166) and the 3-5 elementwise launches

@@ -61,6 +61,36 @@ def test_groupnorm_silu_nhwc(ops, B, C, h, w, G, act, with_add):
     assert torch.equal(y2.reshape(B, h, w, C).permute(0, 3, 1, 2), y)
 
 
+@pytest.mark.parametrize("B,H,L,d", [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160),
+                                     (1, 4, 100, 64), (2, 10, 576, 64), (3, 5, 33, 16), (2, 8, 144, 160), (1, 2, 2304, 40),
+                                     (2, 20, 1024, 64), (1, 1, 1, 8)])
+def test_self_attention(ops, B, H, L, d):
+    """flash self-attention vs torch fp32 softmax(QK^T/sqrt(d))V on the same fp16-representable inputs.
+    Tolerance: P is packed to fp16 for the PV MFMA and the output is fp16: 2e-3 absolute on |out| <= ~1."""
+    g = torch.Generator().manual_seed(L * d + H)
+    qkv = torch.randn(B, L, 3 * H * d, generator=g).half()
+    C = H * d
+    q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))     # strided views of a fused QKV
+    ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2))
+    ref = ref.transpose(1, 2)
+    qc = qkv.cuda()
+    qd, kd, vd = (qc[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+    out = ops.self_attention(qd, kd, vd)
+    assert out.shape == (B, L, H, d) and out.is_contiguous()
+    err = (out.float().cpu() - ref).abs()
+    assert err.max().item() < 2e-3, err.max().item()
+    assert err.mean().item() < 2e-4
+    assert torch.equal(out, ops.self_attention(qd, kd, vd))
+    # a spiked key forces the online-softmax rescale branch late in the sweep (cdna guide rule 26)
+    if L >= 128:
+        k2 = k.clone()
+        k2[:, L - 5] = q[:, 3] * 4.0
+        ref2 = F.scaled_dot_product_attention(q.float().transpose(1, 2), k2.float().transpose(1, 2),
+                                              v.float().transpose(1, 2)).transpose(1, 2)
+        out2 = ops.self_attention(q.cuda(), k2.cuda(), v.cuda())
+        assert (out2.float().cpu() - ref2).abs().max().item() < 3e-3
+
+
 def test_geglu(ops):
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(2, 100, 2 * 1280, generator=g) * 2).half()
