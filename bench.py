@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--regions", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--nondeterministic-conv", action="store_true",
-                    help="let MIOpen pick split-K (atomic) convolution kernels: faster on some shapes, not bit-reproducible")
+    ap.add_argument("--deterministic-conv", action="store_true",
+                    help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
+                         "falls back to kernels >10x slower on this image; off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=1)
     return ap.parse_args()
@@ -184,7 +185,7 @@ def main():
     from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
     from diffusionspatialcontrol_amd.parallel import broadcast_generation_inputs, shard_image_indices
     ops.GRAPHS_ENABLED = not a.no_graph
-    torch.backends.cudnn.deterministic = not a.nondeterministic_conv
+    torch.backends.cudnn.deterministic = bool(a.deterministic_conv)
 
     cfg = UNetConfig.sd15()
     torch.manual_seed(0)

@@ -33,11 +33,17 @@ _SIGNATURES = {
     "dsc_abi_version": (ctypes.c_int, []),
     "dsc_target_arch": (ctypes.c_char_p, []),
     "dsc_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "dsc_debug_set_stamp_buffer": (None, [_vp]),
     "dsc_region_xattn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "dsc_region_xattn_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 7 + [_i64p] * 4 +
                              [ctypes.c_float, _vp, ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, ctypes.c_size_t, _vp]),
     "dsc_region_xattn_std": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_i64p] * 2 +
                              [ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dsc_xattn_kv_pack_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "dsc_xattn_kv_pack": (ctypes.c_int, [_vp] * 3 + [ctypes.c_int] * 4 + [_i64p] * 2 + [ctypes.c_int, _vp]),
+    "dsc_region_xattn_fwd_packed": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 8 + [_i64p] * 2 +
+                                    [ctypes.c_float, _vp, ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp,
+                                     ctypes.c_size_t, _vp]),
     "dsc_self_attn_fwd": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 5 + [_i64p] * 4 + [ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_prepare_unet_input": (ctypes.c_int, [_vp] + [ctypes.c_float] * 3 + [_vp, _vp, _vp] + [ctypes.c_int] * 3 + [_vp]),
     "dsc_cfg_dpmpp2m_step": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_float] * 8 + [_vp, _vp, _vp] +

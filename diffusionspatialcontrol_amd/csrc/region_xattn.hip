@@ -23,120 +23,14 @@
 // workgroup pays ONE memory round trip before its first MFMA instead of one per staging-loop iteration.
 // blockIdx is mapped so that the H heads of one (b, row chunk) share an XCD: they re-read the same region
 // rows and the same 128-B lines of Q from that XCD's L2.
-#include "dsc_common.h"
-#include "dsc_hip.h"
+#include "xattn_shared.h"
+
+using namespace dsc_xattn;
 
 namespace {
 
-constexpr int kSMax = 96;        // key length padded to 3 MFMA row tiles
-typedef short s4_t __attribute__((__vector_size__(4 * sizeof(short))));
-constexpr int kThreads = 256;
-constexpr int kWaves = 4;
-
-struct XattnParams {
-    const half_t* q; const half_t* k; const half_t* v; half_t* out;
-    const float* region;
-    const float* sigma_dev;
-    double* partials;            // [n_groups][npart][2]
-    float* std_out;              // optional [n_groups]
-    float sigma_host, scale;
-    int Bc, H, L, S, d, Bw, n_groups;
-    int nchunks, tiles_per_wave, npart, xcd_map;
-    long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
-    unsigned flags;
-};
-
-__device__ __forceinline__ void block_to_work(const XattnParams& p, int& b, int& h, int& chunk) {
-    const int bid = blockIdx.x;
-    int cg;
-    if (p.xcd_map) {             // (Bc * nchunks) % 8 == 0: the H heads of a chunk sit on one XCD (bid % 8)
-        const int x = bid & 7, j = bid >> 3;
-        h = j % p.H;
-        cg = (j / p.H) * 8 + x;
-    } else {
-        h = bid % p.H;
-        cg = bid / p.H;
-    }
-    b = cg / p.nchunks;
-    chunk = cg % p.nchunks;
-}
-
-template <int NK>
-struct XCfg {
-    static constexpr int DM = (NK + 1) / 2;
-    static constexpr int KP = 16 * NK + 8;                  // K row stride (halves): odd multiple of 16 B
-    static constexpr int VP = (DM <= 3) ? 96 : 160;         // V row stride: tr reads conflict-free ((VP/2) % 64 in {16,48})
-    static constexpr int CH = (kSMax * 2 * NK + kThreads - 1) / kThreads;   // 16-B chunks per thread per operand
-};
-
-__device__ __forceinline__ h4_t tr_read(const half_t* p) {
-    const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (s4_t __attribute__((address_space(3)))*)(const_cast<half_t*>(p)));
-    return __builtin_bit_cast(h4_t, r);
-}
-
-// K[b, :, h, :] (and V) -> registers: chunk idx = s * d8 + c covers 8 halves; all loads issued back to back
-template <int NK, bool WITH_V>
-__device__ __forceinline__ void kv_load(const XattnParams& p, int b, int h, h8_t (&kr)[XCfg<NK>::CH], h8_t (&vr)[XCfg<NK>::CH]) {
-    const half_t* kb = p.k + b * p.ksb + h * p.ksh;
-    const half_t* vb = p.v + b * p.vsb + h * p.vsh;
-    const int d8 = p.d >> 3, n = p.S * d8;
-#pragma unroll
-    for (int c = 0; c < XCfg<NK>::CH; ++c) {
-        const int idx = threadIdx.x + c * kThreads;
-        if (idx < n) {
-            const int s = idx / d8, col = idx - s * d8;
-            kr[c] = *reinterpret_cast<const h8_t*>(kb + s * p.kss + col * 8);
-            if (WITH_V) vr[c] = *reinterpret_cast<const h8_t*>(vb + s * p.vss + col * 8);
-        }
-    }
-}
-
-// registers -> LDS images Ks[96][KP] / Vs[96][VP] (row-major), plus the few zeros the MFMAs need:
-//   K columns [d, 16*NK): the Q fragment is zero there, but 0 * (NaN garbage) would poison the score;
-//   V rows [S, 16*ceil(S/16)): P is exactly 0 there, same reason.  K rows >= S only feed scores that are replaced by
-//   -inf (a select, not arithmetic) and V columns >= d only feed output rows that are never stored: left as they are.
-template <int NK, bool WITH_V>
-__device__ __forceinline__ void kv_store(const XattnParams& p, half_t* Ks, half_t* Vs, const h8_t (&kr)[XCfg<NK>::CH],
-                                         const h8_t (&vr)[XCfg<NK>::CH]) {
-    constexpr int KP = XCfg<NK>::KP, VP = XCfg<NK>::VP;
-    const int d8 = p.d >> 3, n = p.S * d8;
-#pragma unroll
-    for (int c = 0; c < XCfg<NK>::CH; ++c) {
-        const int idx = threadIdx.x + c * kThreads;
-        if (idx < n) {
-            const int s = idx / d8, col = idx - s * d8;
-            *reinterpret_cast<h8_t*>(Ks + s * KP + col * 8) = kr[c];
-            if (WITH_V) *reinterpret_cast<h8_t*>(Vs + s * VP + col * 8) = vr[c];
-        }
-    }
-    const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        const int padc = 2 * NK - d8;                        // 16-byte pad chunks per row (0 when d == 16*NK)
-        for (int idx = threadIdx.x; idx < kSMax * padc; idx += kThreads)
-            *reinterpret_cast<h8_t*>(Ks + (idx / padc) * KP + p.d + (idx % padc) * 8) = z;
-    }
-    if (WITH_V) {
-        const int zrows = ((p.S + 15) & ~15) - p.S, v8 = VP / 8;
-        for (int idx = threadIdx.x; idx < zrows * v8; idx += kThreads)
-            *reinterpret_cast<h8_t*>(Vs + (p.S + idx / v8) * VP + (idx % v8) * 8) = z;
-    }
-}
-
-template <int NK>
-__device__ __forceinline__ void load_q_frags(const XattnParams& p, h8_t (&qf)[NK], int b, int h, int row, int hh) {
-    const half_t* qb = p.q + b * p.qsb + h * p.qsh + (long long)row * p.qsl;
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        const int col = 16 * ks + 8 * hh;
-        h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (col < p.d) val = *reinterpret_cast<const h8_t*>(qb + col);
-        qf[ks] = val;
-    }
-}
-
 // scores of one 32-row tile: acc[m] element i <-> s = 32m + (i & 3) + 8 (i >> 2) + 4 hh, l = lane & 31
-template <int NK, bool REF16>
+template <int NK, bool REF16, bool RAW = false>
 __device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, const h8_t (&qf)[NK], f16x_t (&acc)[3],
                                        int r, int hh, float scale) {
     constexpr int KP = XCfg<NK>::KP;
@@ -156,7 +50,7 @@ __device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, c
         for (int i = 0; i < 16; ++i) {
             // attention_modify.py:90 - the matmul result is an fp16 tensor, then * scale_factor rounds again
             if (REF16) acc[m][i] = round_f16(round_f16(acc[m][i]) * scale);
-            else acc[m][i] = acc[m][i] * scale;
+            else if (!RAW) acc[m][i] = acc[m][i] * scale;
         }
     }
 }
@@ -170,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
     double* red = reinterpret_cast<double*>(smem + kSMax * KP * 2);
     int b, h, chunk;
     block_to_work(p, b, h, chunk);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
     h8_t kr[XCfg<NK>::CH], vr[XCfg<NK>::CH];
     kv_load<NK, false>(p, b, h, kr, vr);
     h8_t qf[NK];
@@ -216,38 +110,10 @@ __global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
     }
 }
 
-// group std from the partials: every thread of the block gets the same value (fixed summation order).
-// Split in two so that the partial loads are in flight together with the K / V / Q loads of the prologue.
-__device__ __forceinline__ void group_partials(const XattnParams& p, int g, double& a1, double& a2) {
-    const double* src = p.partials + (long long)g * p.npart * 2;
-    a1 = 0.0; a2 = 0.0;
-    for (int i = threadIdx.x; i < p.npart; i += kThreads) { a1 += src[2 * i]; a2 += src[2 * i + 1]; }
-}
-__device__ __forceinline__ float group_std_finish(const XattnParams& p, double a1, double a2, double* red, bool ref16) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    a1 = wave_sum_f64(a1);
-    a2 = wave_sum_f64(a2);
-    if (lane == 0) { red[2 * wave] = a1; red[2 * wave + 1] = a2; }
-    __syncthreads();
-    double t1 = 0.0, t2 = 0.0;
-    for (int w = 0; w < kWaves; ++w) { t1 += red[2 * w]; t2 += red[2 * w + 1]; }
-    const double n = (double)(p.Bc / p.n_groups) * p.H * (double)p.L * p.S;
-    double var = (t2 - t1 * t1 / n) / (n - 1.0);             // unbiased, torch.std default
-    var = var > 0.0 ? var : 0.0;
-    float sd = (float)sqrt(var);
-    if (ref16) sd = round_f16(sd);                           // std of an fp16 tensor is a 0-dim fp16 tensor
-    return sd;
-}
-__device__ __forceinline__ float group_std(const XattnParams& p, int g, double* red, bool ref16) {
-    double a1, a2;
-    group_partials(p, g, a1, a2);
-    return group_std_finish(p, a1, a2, red, ref16);
-}
-
 // finalises std_out[g] for dsc_region_xattn_std (one block per group)
 template <bool REF16>
 __global__ __launch_bounds__(kThreads) void xattn_std_finalize(XattnParams p) {
-    __shared__ double red[2 * kWaves];
+    __shared__ double red[kRedBytes / 8];
     const float sd = group_std(p, blockIdx.x, red, REF16);
     if (threadIdx.x == 0) p.std_out[blockIdx.x] = sd;
 }
@@ -256,18 +122,18 @@ __global__ __launch_bounds__(kThreads) void xattn_std_finalize(XattnParams p) {
 constexpr int kWCH = (32 * kSMax / 4 + 63) / 64;             // float4 chunks per lane of one 32 x S region tile (12)
 
 template <int NK, bool REF16>
-__global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
+__global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xattn_fwd(XattnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = XCfg<NK>;
     constexpr int KP = C::KP, VP = C::VP, DM = C::DM;
     half_t* Ks = reinterpret_cast<half_t*>(smem);
     half_t* Vs = Ks + kSMax * KP;
     double* red = reinterpret_cast<double*>(Vs + kSMax * VP);
-    float* Wt_all = reinterpret_cast<float*>(red + 2 * kWaves);
+    float* Wt_all = reinterpret_cast<float*>(red + kRedBytes / 8);
     int b, h, chunk;
     block_to_work(p, b, h, chunk);
     if (p.flags & 8u) return;                                // DEBUG timing probe: launch floor
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
     const bool has_bias = p.region != nullptr;
     const bool need_std = has_bias && !(p.flags & DSC_FLAG_BIAS_IS_FINAL);
     const int wt_stride = (32 * p.S + 3) & ~3;
@@ -343,44 +209,12 @@ __global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
         if (p.flags & 16u) return;                           // DEBUG timing probe: prologue only
         if (tile_ok) {
             f16x_t acc[3];
-            scores<NK, REF16>(p, Ks, qf, acc, r, hh, p.scale);
-            const float* wrow = Wt + min(r, nrows - 1) * p.S;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int s = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                    float a = acc[m][i];
-                    if (m < mt && s < p.S) {
-                        if (has_bias) {
-                            const float bias = (wrow[s] * sig) * sd;        // w * sigma * std, fp32 (app.py:1004)
-                            a = a + bias;                                   // attention_modify.py:97
-                            if (REF16) a = round_f16(a);
-                        }
-                    } else {
-                        a = -INFINITY;
-                    }
-                    acc[m][i] = a;
-                    mx = fmaxf(mx, a);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = __expf(acc[m][i] - mx);
-                    acc[m][i] = e;
-                    sum += e;
-                }
-            sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.f / sum;
-            h8_t pf[6];                                      // softmax output is an fp16 tensor (:101)
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)(acc[m][i] * inv);
+            scores<NK, REF16, !REF16>(p, Ks, qf, acc, r, hh, p.scale);
+            h8_t pf[6];
+            float oscale = 1.f;
+            const float* brow = has_bias ? Wt + min(r, nrows - 1) * p.S : nullptr;
+            if (REF16) softmax_tile<REF16, false>(acc, pf, brow, sig, sd, p.S, hh);
+            else oscale = softmax_tile_lean<false>(acc, pf, brow, sig, sd, p.scale * 1.4426950408889634f, p.S, hh);
 
             half_t* ob = p.out + b * p.osb + h * p.osh + (long long)row * p.osl;
             const bool row_ok = l0 + r < p.L;
@@ -404,8 +238,8 @@ __global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
                     for (int g4 = 0; g4 < 4; ++g4) {
                         const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
                         if (row_ok && dd0 < p.d) {
-                            const h4_t ov = {(half_t)o[4 * g4], (half_t)o[4 * g4 + 1], (half_t)o[4 * g4 + 2],
-                                             (half_t)o[4 * g4 + 3]};
+                            const h4_t ov = {(half_t)(o[4 * g4] * oscale), (half_t)(o[4 * g4 + 1] * oscale),
+                                             (half_t)(o[4 * g4 + 2] * oscale), (half_t)(o[4 * g4 + 3] * oscale)};
                             *reinterpret_cast<h4_t*>(ob + dd0) = ov;
                         }
                     }
@@ -419,12 +253,12 @@ __global__ __launch_bounds__(kThreads) void xattn_fwd(XattnParams p) {
 template <int NK>
 size_t fwd_lds_bytes(int S) {
     const int wt_stride = (32 * S + 3) & ~3;
-    return (size_t)kSMax * XCfg<NK>::KP * 2 + (size_t)kSMax * XCfg<NK>::VP * 2 + 2 * kWaves * 8 +
+    return (size_t)kSMax * XCfg<NK>::KP * 2 + (size_t)kSMax * XCfg<NK>::VP * 2 + kRedBytes +
            (size_t)kWaves * wt_stride * 4;
 }
 template <int NK>
 size_t stats_lds_bytes() {
-    return (size_t)kSMax * XCfg<NK>::KP * 2 + 2 * kWaves * 8;
+    return (size_t)kSMax * XCfg<NK>::KP * 2 + kRedBytes;
 }
 
 int pick_nk(int d) {
@@ -433,20 +267,11 @@ int pick_nk(int d) {
     return 0;
 }
 
-void plan(XattnParams& p) {
-    // one wave = one 32-row tile; a workgroup = 4 waves x tiles_per_wave tiles of one (b, h)
-    const int tiles = (p.L + 31) / 32;
-    int tpw = 1;
-    while (tpw < 4 && (long long)p.Bc * p.H * ((tiles + 4 * tpw - 1) / (4 * tpw)) > 2048) tpw *= 2;
-    p.tiles_per_wave = tpw;
-    p.nchunks = (tiles + 4 * tpw - 1) / (4 * tpw);
-    p.npart = (p.Bc / p.n_groups) * p.H * p.nchunks;
-    p.xcd_map = ((p.Bc * p.nchunks) % 8 == 0) ? 1 : 0;
-}
+void plan(XattnParams& p) { plan_tiles(p); }
 
 template <int NK, bool REF16>
 int launch_stats(const XattnParams& p, hipStream_t st) {
-    const dim3 grid(p.Bc * p.H * p.nchunks), block(kThreads);
+    const dim3 grid = xattn_grid(p), block(kThreads);
     hipLaunchKernelGGL((xattn_stats<NK, REF16>), grid, block, stats_lds_bytes<NK>(), st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
@@ -459,7 +284,7 @@ int launch_fwd(const XattnParams& p, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    const dim3 grid(p.Bc * p.H * p.nchunks), block(kThreads);
+    const dim3 grid = xattn_grid(p), block(kThreads);
     hipLaunchKernelGGL((xattn_fwd<NK, REF16>), grid, block, lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -1,0 +1,270 @@
+// Device helpers shared by the region cross-attention kernels (region_xattn.hip: generic operands;
+// region_xattn_packed.hip: pre-packed K/V + compressed region table).
+#pragma once
+#include "dsc_common.h"
+#include "dsc_hip.h"
+
+namespace dsc_xattn {
+
+constexpr int kSMax = 96;        // key length padded to 3 MFMA row tiles
+typedef short s4_t __attribute__((__vector_size__(4 * sizeof(short))));
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kRedBytes = (2 * kThreads + 32) * 8;       // LDS scratch of the fp64 reductions
+
+struct XattnParams {
+    const half_t* q; const half_t* k; const half_t* v; half_t* out;
+    const float* region;
+    const float* sigma_dev;
+    double* partials;            // [n_groups][npart][2]
+    float* std_out;              // optional [n_groups]
+    float sigma_host, scale;
+    int Bc, H, L, S, d, Bw, n_groups;
+    int nchunks, tiles_per_wave, npart, xcd_map;
+    long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
+    unsigned flags;
+};
+
+// grid = (8, H, Bc*nchunks/8) when Bc*nchunks % 8 == 0, else (1, H, Bc*nchunks).  The hardware deals linear workgroup
+// ids x + 8*(y + H*z) round-robin over the 8 XCDs, so the H heads (y) of one (b, row chunk) = (z, x) share an XCD and
+// re-read the same region rows / Q lines from that XCD's L2 - with no integer division except b = cg / nchunks.
+__device__ __forceinline__ void block_to_work(const XattnParams& p, int& b, int& h, int& chunk) {
+    h = blockIdx.y;
+    const int cg = blockIdx.z * gridDim.x + blockIdx.x;
+    b = cg / p.nchunks;
+    chunk = cg - b * p.nchunks;
+}
+inline dim3 xattn_grid(const XattnParams& p) {
+    const int ncg = p.Bc * p.nchunks;
+    return (ncg % 8 == 0) ? dim3(8, p.H, ncg / 8) : dim3(1, p.H, ncg);
+}
+
+template <int NK>
+struct XCfg {
+    static constexpr int DM = (NK + 1) / 2;
+    static constexpr int KP = 16 * NK + 8;                  // K row stride (halves): odd multiple of 16 B
+    static constexpr int VP = (DM <= 3) ? 96 : 160;         // V row stride: tr reads conflict-free ((VP/2) % 64 in {16,48})
+    static constexpr int CH = (kSMax * 2 * NK + kThreads - 1) / kThreads;   // 16-B chunks per thread per operand
+};
+
+__device__ __forceinline__ h4_t tr_read(const half_t* p) {
+    const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s4_t __attribute__((address_space(3)))*)(const_cast<half_t*>(p)));
+    return __builtin_bit_cast(h4_t, r);
+}
+
+// K[b, :, h, :] (and V) -> registers: chunk idx = s * d8 + c covers 8 halves; all loads issued back to back
+template <int NK, bool WITH_V>
+__device__ __forceinline__ void kv_load(const XattnParams& p, int b, int h, h8_t (&kr)[XCfg<NK>::CH], h8_t (&vr)[XCfg<NK>::CH]) {
+    const half_t* kb = p.k + b * p.ksb + h * p.ksh;
+    const half_t* vb = p.v + b * p.vsb + h * p.vsh;
+    const int d8 = p.d >> 3, n = p.S * d8;
+#pragma unroll
+    for (int c = 0; c < XCfg<NK>::CH; ++c) {
+        const int idx = threadIdx.x + c * kThreads;
+        if (idx < n) {
+            const int s = idx / d8, col = idx - s * d8;
+            kr[c] = *reinterpret_cast<const h8_t*>(kb + s * p.kss + col * 8);
+            if (WITH_V) vr[c] = *reinterpret_cast<const h8_t*>(vb + s * p.vss + col * 8);
+        }
+    }
+}
+
+// registers -> LDS images Ks[96][KP] / Vs[96][VP] (row-major), plus the few zeros the MFMAs need:
+//   K columns [d, 16*NK): the Q fragment is zero there, but 0 * (NaN garbage) would poison the score;
+//   V rows [S, 16*ceil(S/16)): P is exactly 0 there, same reason.  K rows >= S only feed scores that are replaced by
+//   -inf (a select, not arithmetic) and V columns >= d only feed output rows that are never stored: left as they are.
+template <int NK, bool WITH_V>
+__device__ __forceinline__ void kv_store(const XattnParams& p, half_t* Ks, half_t* Vs, const h8_t (&kr)[XCfg<NK>::CH],
+                                         const h8_t (&vr)[XCfg<NK>::CH]) {
+    constexpr int KP = XCfg<NK>::KP, VP = XCfg<NK>::VP;
+    const int d8 = p.d >> 3, n = p.S * d8;
+#pragma unroll
+    for (int c = 0; c < XCfg<NK>::CH; ++c) {
+        const int idx = threadIdx.x + c * kThreads;
+        if (idx < n) {
+            const int s = idx / d8, col = idx - s * d8;
+            *reinterpret_cast<h8_t*>(Ks + s * KP + col * 8) = kr[c];
+            if (WITH_V) *reinterpret_cast<h8_t*>(Vs + s * VP + col * 8) = vr[c];
+        }
+    }
+    const h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const int padc = 2 * NK - d8;                        // 16-byte pad chunks per row (0 when d == 16*NK)
+        for (int idx = threadIdx.x; idx < kSMax * padc; idx += kThreads)
+            *reinterpret_cast<h8_t*>(Ks + (idx / padc) * KP + p.d + (idx % padc) * 8) = z;
+    }
+    if (WITH_V) {
+        const int zrows = ((p.S + 15) & ~15) - p.S, v8 = VP / 8;
+        for (int idx = threadIdx.x; idx < zrows * v8; idx += kThreads)
+            *reinterpret_cast<h8_t*>(Vs + (p.S + idx / v8) * VP + (idx % v8) * 8) = z;
+    }
+}
+
+template <int NK>
+__device__ __forceinline__ void load_q_frags(const XattnParams& p, h8_t (&qf)[NK], int b, int h, int row, int hh) {
+    const half_t* qb = p.q + b * p.qsb + h * p.qsh + (long long)row * p.qsl;
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        const int col = 16 * ks + 8 * hh;
+        h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (col < p.d) val = *reinterpret_cast<const h8_t*>(qb + col);
+        qf[ks] = val;
+    }
+}
+
+// group std from the partials: every thread of the block gets the same value (fixed summation order).
+// Split in two so that the partial loads are in flight together with the K / V / Q loads of the prologue.
+__device__ __forceinline__ void group_partials(const XattnParams& p, int g, double& a1, double& a2) {
+    const double* src = p.partials + (long long)g * p.npart * 2;
+    a1 = 0.0; a2 = 0.0;
+    for (int i = threadIdx.x; i < p.npart; i += kThreads) { a1 += src[2 * i]; a2 += src[2 * i + 1]; }
+}
+// `red` needs 2 * kThreads doubles of LDS.  Tree through LDS instead of 12 dependent ds_bpermute shuffles of doubles:
+// every thread stores its pair, 8 threads each add 32 pairs in a fixed order, then everyone adds those 8.
+__device__ __forceinline__ float group_std_finish(const XattnParams& p, double a1, double a2, double* red, bool ref16) {
+    red[2 * threadIdx.x] = a1;
+    red[2 * threadIdx.x + 1] = a2;
+    __syncthreads();
+    double* red2 = red + 2 * kThreads;                       // 256 -> 16 (each of 16 threads adds 16 pairs) -> all add 16
+    if (threadIdx.x < 16) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < kThreads / 16; ++i) { s1 += red[2 * (threadIdx.x * 16 + i)]; s2 += red[2 * (threadIdx.x * 16 + i) + 1]; }
+        red2[2 * threadIdx.x] = s1; red2[2 * threadIdx.x + 1] = s2;
+    }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { t1 += red2[2 * w]; t2 += red2[2 * w + 1]; }
+    const double n = (double)(p.Bc / p.n_groups) * p.H * (double)p.L * p.S;
+    double var = (t2 - t1 * t1 / n) / (n - 1.0);             // unbiased, torch.std default
+    var = var > 0.0 ? var : 0.0;
+    float sd = (float)sqrt(var);
+    if (ref16) sd = round_f16(sd);                           // std of an fp16 tensor is a 0-dim fp16 tensor
+    return sd;
+}
+__device__ __forceinline__ float group_std(const XattnParams& p, int g, double* red, bool ref16) {
+    double a1, a2;
+    group_partials(p, g, a1, a2);
+    return group_std_finish(p, a1, a2, red, ref16);
+}
+
+
+// Bias of the 4 consecutive keys 32m + 8g + 4hh + {0..3} of this lane's row.  VEC: the row lives in LDS with a
+// 16-byte-aligned base and zero padding up to key 99 (packed kernel: one ds_read_b128); else scalar, address clamped.
+template <bool VEC>
+__device__ __forceinline__ void bias4(const float* brow, int s0, int smax, float (&out)[4]) {
+    if (VEC) {
+        const f4x_t v = *reinterpret_cast<const f4x_t*>(brow + s0);
+        out[0] = v[0]; out[1] = v[1]; out[2] = v[2]; out[3] = v[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = brow[min(s0 + j, smax)];
+    }
+}
+
+// Biased softmax of one 32-row score tile, branch-free.  acc[m][i] holds score (key s = 32m + (i&3) + 8(i>>2) + 4hh,
+// query row = lane & 31) on entry; on exit pf[] holds the fp16 probabilities packed as the B operand of the PV MFMA.
+// brow: this lane's bias row in LDS (nullptr = no bias, wave-uniform); bias = (brow[s] * mul1) * mul2 (mul1 = sigma,
+// mul2 = std for a raw table; 1, 1 for a table that already holds the final bias).
+template <bool REF16, bool VEC>
+__device__ __forceinline__ void softmax_tile(f16x_t (&acc)[3], h8_t (&pf)[6], const float* brow, float mul1, float mul2,
+                                             int S, int hh) {
+    const int smax = S - 1;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (brow) bias4<VEC>(brow, 32 * m + 8 * g + 4 * hh, smax, bias);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * g + j, s = 32 * m + 8 * g + 4 * hh + j;
+                float a = acc[m][i];
+                if (brow) {
+                    a = a + (bias[j] * mul1) * mul2;                // w * sigma * std, fp32 (app.py:1004, :97)
+                    if (REF16) a = round_f16(a);
+                }
+                a = s < S ? a : -INFINITY;                          // select, not a branch
+                acc[m][i] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __expf(acc[m][i] - mx);
+            acc[m][i] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)(acc[m][i] * inv);   // fp16 tensor (:101)
+}
+
+// Lean variant for fp32 scores (no fp16-rounding emulation): acc holds the RAW q.k products.  Works in base 2:
+// a2 = acc * (scale*log2e) + bias2, p = exp2(a2 - max) left UNNORMALISED in pf (values <= 1);
+// the caller multiplies the 16 PV outputs per channel tile by the returned 1/sum instead of 48 probabilities.
+// bias2 = ((brow[s] * mul1) * mul2) * log2e.
+template <bool VEC>
+__device__ __forceinline__ float softmax_tile_lean(f16x_t (&acc)[3], h8_t (&pf)[6], const float* brow, float mul1,
+                                                   float mul2, float scale_log2e, int S, int hh) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    const int smax = S - 1;
+    const float mm = mul2 * kLog2e;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (brow) bias4<VEC>(brow, 32 * m + 8 * g + 4 * hh, smax, bias);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * g + j, s = 32 * m + 8 * g + 4 * hh + j;
+                float a = acc[m][i] * scale_log2e;
+                if (brow) a = fmaf(bias[j] * mul1, mm, a);
+                a = s < S ? a : -INFINITY;
+                acc[m][i] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(acc[m][i] - mx);    // exp2(-inf) = 0 for masked keys
+            acc[m][i] = e;
+            sum += e;
+        }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)acc[m][i];
+    sum += __shfl_xor(sum, 32, 64);
+    return 1.f / sum;
+}
+
+// plan shared by all entry points: one wave = one 32-row tile; a workgroup = 4 waves x tiles_per_wave tiles of one (b, h)
+inline void plan_tiles(XattnParams& p, int tiles_per_wave_hint = 0) {
+    const int tiles = (p.L + 31) / 32;
+    int tpw = 1;
+    if (tiles_per_wave_hint > 0) tpw = tiles_per_wave_hint;
+    else while (tpw < 4 && (long long)p.Bc * p.H * ((tiles + 4 * tpw - 1) / (4 * tpw)) > 2048) tpw *= 2;
+    p.tiles_per_wave = tpw;
+    p.nchunks = (tiles + 4 * tpw - 1) / (4 * tpw);
+    p.npart = (p.Bc / p.n_groups) * p.H * p.nchunks;
+    p.xcd_map = ((p.Bc * p.nchunks) % 8 == 0) ? 1 : 0;
+}
+
+}  // namespace dsc_xattn

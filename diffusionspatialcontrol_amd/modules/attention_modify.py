@@ -83,6 +83,23 @@ def resident_table(w, device):
     return dw
 
 
+_COMPRESSED_CACHE = OrderedDict()
+
+
+def compressed_table(w, device):
+    """(ids, rows) of ops.compress_region_table for a region table, or None when it has too many distinct rows;
+    computed once per (tensor object, version, device) like resident_table."""
+    key = (id(w), w._version, str(device))
+    hit = _COMPRESSED_CACHE.get(key)
+    if hit is not None and hit[0] is w:
+        return hit[1]
+    comp = ops.compress_region_table(resident_table(w, device))
+    _COMPRESSED_CACHE[key] = (w, comp)
+    while len(_COMPRESSED_CACHE) > 64:
+        _COMPRESSED_CACHE.popitem(last=False)
+    return comp
+
+
 _SIGMA_CACHE = OrderedDict()
 
 
@@ -105,10 +122,14 @@ def _sigma_arg(sigma, device):
     return s32
 
 
-def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None):
+def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None):
     w_dev = resident_table(w, q.device)
-    ref16 = q.dtype == torch.float16
     if weight_func is None or weight_func_is_default(weight_func):
+        if packed_kv is not None and layout == "blhd":
+            comp = compressed_table(w, q.device)
+            if comp is not None:                 # prepared operands: packed text K/V + row-id region table
+                return ops.region_xattn_packed(q, packed_kv, k.shape[1], comp, _sigma_arg(sigma, q.device),
+                                               n_std_groups=n_std_groups, scale=scale, ref_fp16_rounding=ref16)
         return ops.region_xattn(q, k, v, w_dev, _sigma_arg(sigma, q.device), layout=layout, n_std_groups=n_std_groups,
                                 scale=scale, ref_fp16_rounding=ref16)
     # generic weight_func: evaluate it the way the reference does (attention_modify.py:90-95), then let the kernel
@@ -127,7 +148,8 @@ def scaled_dot_product_attention_regionstate(query, key, value, attn_mask=None, 
     """Same signature and result as attention_modify.py:74-103; query [Bc,H,L,d], key/value [Bc,H,S,d]."""
     if attn_mask is not None or is_causal or dropout_p != 0.0:
         raise NotImplementedError("attn_mask / is_causal / dropout are not on the hot path (never used by app.py)")
-    return _region_attention(query, key, value, region_state, sigma, weight_func, "bhld", n_std_groups, scale)
+    return _region_attention(query, key, value, region_state, sigma, weight_func, "bhld", n_std_groups, scale,
+                             ref16=query.dtype == torch.float16)
 
 
 def get_attention_scores(attn, query, key, attention_mask=None):
@@ -143,11 +165,14 @@ class _RegionProcessor:
 
     honours_attn_scale = False
 
-    def __init__(self, n_std_groups: int = 1):
+    def __init__(self, n_std_groups: int = 1, ref_fp16_rounding: bool = False):
         # 1 = the reference: ONE std over the whole call (all rows, all heads).  The pipeline sets B when it
         # micro-batches B images in the row layout [u_0..u_{B-1}, c_0..c_{B-1}] so that each image keeps the std
         # group the reference's one-image-per-call k-diffusion path gives it.
         self.n_std_groups = n_std_groups
+        # False: scores stay fp32 inside the kernel (the parity target is the reference's CPU fp32 pipeline).
+        # True: round where the reference's fp16 GPU tensors round (scores, std, bias add, softmax) - ~15 % slower.
+        self.ref_fp16_rounding = ref_fp16_rounding
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states=None,
                  attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, scale: float = 1.0,
@@ -167,6 +192,7 @@ class _RegionProcessor:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
         is_self = encoder_hidden_states is None
         H = attn.heads
+        packed_kv = None
         fused_qkv = getattr(attn, "qkv_weight", None)
         if is_self and fused_qkv is not None and attn.to_q.bias is None:
             # self-attention: q, k, v from ONE [3C, C] GEMM; the three [B, L, H, d] operands are strided views of it
@@ -185,6 +211,7 @@ class _RegionProcessor:
             cache = getattr(attn, "kv_cache", None)
             if cache is not None and cache["src"] is encoder_hidden_states:
                 key, value = cache["k"], cache["v"]          # text K/V: once per generation, not once per step
+                packed_kv = cache.get("packed")
             else:
                 key = attn.to_k(encoder_hidden_states)
                 value = attn.to_v(encoder_hidden_states)
@@ -197,9 +224,12 @@ class _RegionProcessor:
             w = region_prompt["region_state"][img_sequence_length]          # KeyError when L is not a level (:481)
             groups = region_prompt.get("n_std_groups", self.n_std_groups)
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
-                                    groups, sc)
+                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv)
         elif not is_self:
-            out = ops.region_xattn(q4, k4, v4, None, layout="blhd", scale=sc, ref_fp16_rounding=False)
+            if packed_kv is not None:
+                out = ops.region_xattn_packed(q4, packed_kv, S, None, scale=sc, ref_fp16_rounding=False)
+            else:
+                out = ops.region_xattn(q4, k4, v4, None, layout="blhd", scale=sc, ref_fp16_rounding=False)
         else:
             out = ops.self_attention(q4, k4, v4, scale=sc)                  # [B, L, H, d]
         hidden_states = out.reshape(B, L, C)
@@ -223,9 +253,9 @@ class AttnProcessor(_RegionProcessor, nn.Module):
     r"""Counterpart of reference `AttnProcessor` (:106-207): scores use `attn.scale` (:57-63)."""
     honours_attn_scale = True
 
-    def __init__(self, n_std_groups: int = 1):
+    def __init__(self, n_std_groups: int = 1, ref_fp16_rounding: bool = False):
         nn.Module.__init__(self)
-        _RegionProcessor.__init__(self, n_std_groups)
+        _RegionProcessor.__init__(self, n_std_groups, ref_fp16_rounding)
 
     def forward(self, *a, **k):
         return _RegionProcessor.__call__(self, *a, **k)

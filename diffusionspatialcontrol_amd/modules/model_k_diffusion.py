@@ -285,12 +285,18 @@ class StableDiffusionPipeline:
         for m in self.unet.modules():
             if isinstance(m, Attention) and m.is_cross_attention:
                 k, v = m.to_k(text), m.to_v(text)
+                B, S, C = k.shape
+                d = C // m.heads
                 c = m.kv_cache
                 if c is not None and c["src"] is text and c["k"].shape == k.shape:
                     c["k"].copy_(k)
                     c["v"].copy_(v)
                 else:
-                    m.kv_cache = {"src": text, "k": k, "v": v}
+                    c = m.kv_cache = {"src": text, "k": k, "v": v, "packed": None}
+                # MFMA-fragment image of K / V^T for the fused kernel (rewritten in place: captured graphs keep reading it)
+                if S <= 96 and d % 8 == 0 and d <= 160:
+                    c["packed"] = ops.xattn_kv_pack(c["k"].view(B, S, m.heads, d), c["v"].view(B, S, m.heads, d),
+                                                    out=c.get("packed"))
 
     def _drop_text_kv(self):
         from .u_net_condition_modify import Attention

@@ -14,6 +14,10 @@ def _stream_ptr(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
 def _i64x3(a, b, c):
     return (ctypes.c_int64 * 3)(a, b, c)
 
@@ -96,6 +100,66 @@ def region_xattn(q, k, v, region=None, sigma=1.0, *, layout="bhld", n_std_groups
     return out
 
 
+def xattn_kv_pack(k, v, *, layout="blhd", out=None):
+    """Pack cross-attention K / V ([Bc,S,H,d] views, or [Bc,H,S,d] with layout='bhld') into the MFMA-fragment image
+    of dsc_xattn_kv_pack (once per generation: text keys/values are step-invariant)."""
+    _require_gpu(k, v)
+    lib = _lib.load_library()
+    lay = "bhld" if layout == "bhld" else "blc"
+    ks, (Bc, H, S, d) = _blhd_strides(k, lay)
+    vs, _ = _blhd_strides(v, lay)
+    nbytes = lib.dsc_xattn_kv_pack_bytes(Bc, H, S, d)
+    if nbytes == 0:
+        raise _lib.DscLibraryError(f"xattn_kv_pack: unsupported shape S={S}, d={d}")
+    if out is None or out.numel() * 2 != nbytes:
+        out = torch.empty(nbytes // 2, dtype=torch.float16, device=k.device)
+    rc = lib.dsc_xattn_kv_pack(_p(k), _p(v), _p(out), Bc, H, S, d, _i64x3(*ks), _i64x3(*vs), 0, _stream_ptr(k))
+    _lib.check(rc, "dsc_xattn_kv_pack")
+    return out
+
+
+MAX_REGION_ROWS = 32
+
+
+def compress_region_table(w):
+    """dense fp32 [Bw, L, S] -> (ids uint16 [Bw, L], rows fp32 [NU, S]) with rows = the distinct table rows, or None
+    when there are more than MAX_REGION_ROWS of them.  Host/torch work, once per table (lossless: ids index rows)."""
+    Bw, L, S = w.shape
+    rows, inv = torch.unique(w.reshape(Bw * L, S), dim=0, return_inverse=True)
+    if rows.shape[0] > MAX_REGION_ROWS:
+        return None
+    return inv.reshape(Bw, L).to(torch.int16).contiguous(), rows.contiguous()
+
+
+def region_xattn_packed(q, packed_kv, S, region=None, sigma=1.0, *, n_std_groups=1, scale=None, ref_fp16_rounding=True,
+                        out=None, reuse_stats=False, debug_flags=0):
+    """dsc_region_xattn_fwd_packed: q [Bc,L,H,d] view, packed_kv from xattn_kv_pack, region = (ids, rows) from
+    compress_region_table (device tensors) or None -> out [Bc,L,H,d] contiguous."""
+    _require_gpu(q, packed_kv)
+    lib = _lib.load_library()
+    qs, (Bc, H, L, d) = _blhd_strides(q, "blc")
+    if out is None:
+        out = torch.empty((Bc, L, H, d), dtype=q.dtype, device=q.device)
+    os_, _ = _blhd_strides(out, "blc")
+    ids = rows = None
+    Bw = nrows = 0
+    if region is not None:
+        ids, rows = region
+        Bw, nrows = ids.shape[0], rows.shape[0]
+    sig_host, sig_dev = 0.0, None
+    if isinstance(sigma, torch.Tensor) and sigma.is_cuda and sigma.dtype == torch.float32:
+        sig_dev = ctypes.c_void_p(sigma.data_ptr())
+    else:
+        sig_host = float(sigma)
+    flags = (FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0) | (FLAG_REUSE_STATS if reuse_stats else 0) | debug_flags
+    ws = _workspace(q.device, lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups))
+    rc = lib.dsc_region_xattn_fwd_packed(_p(q), _p(packed_kv), _p(out), _p(ids), _p(rows), nrows, Bc, H, L, S, d, Bw,
+                                         n_std_groups, _i64x3(*qs), _i64x3(*os_), sig_host, sig_dev,
+                                         float(scale) if scale else 0.0, 0, flags, _p(ws), ws.numel() * 8, _stream_ptr(q))
+    _lib.check(rc, "dsc_region_xattn_fwd_packed")
+    return out
+
+
 def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp16_rounding=True):
     """std of scale*q.k^T per std group (dsc_region_xattn_std) -> fp32 CUDA tensor [n_std_groups]."""
     _require_gpu(q, k)
@@ -134,10 +198,6 @@ def self_attention(q, k, v, scale=None, out=None):
         float(scale) if scale else 0.0, 0, _stream_ptr(q))
     _lib.check(rc, "dsc_self_attn_fwd")
     return out
-
-
-def _p(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
 def groupnorm_silu(x, groups, weight, bias, eps, act):

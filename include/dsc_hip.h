@@ -45,6 +45,9 @@ extern "C" {
 int dsc_abi_version(void);
 /* Static string naming the code-object target the library was built for ("gfx950"). */
 const char* dsc_target_arch(void);
+/* Diagnostic builds only: a 2-KiB device buffer that receives in-kernel clock stamps of workgroup 0 when a
+ * call carries debug flag 32 (tools/mb_xattn.py); NULL (default) disables it.  No output tensor is ever touched. */
+void dsc_debug_set_stamp_buffer(void* device_buffer_2KiB);
 /* Human-readable text for a status code. */
 const char* dsc_status_string(int status);
 
@@ -92,6 +95,33 @@ int dsc_region_xattn_std(const void* q, const void* k,
                          const int64_t q_strides[3], const int64_t k_strides[3], float scale,
                          int dtype, unsigned flags, float* std_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Prepared-operand path of the region cross-attention (the one the pipeline uses).
+ *
+ * dsc_xattn_kv_pack: the text keys / values of a cross-attention layer are step-invariant (the reference re-projects
+ * them in every layer at every step, attention_modify.py:465-466); they are packed once per generation into the
+ * register image the MFMAs consume (zero-padded K fragments, V^T fragments in the chained product's k order).
+ * `packed` holds dsc_xattn_kv_pack_bytes() bytes, 16-byte aligned; k / v addressed as in dsc_region_xattn_fwd.
+ *
+ * dsc_region_xattn_fwd_packed: same result as dsc_region_xattn_fwd, with
+ *   packed_kv   : the image written by dsc_xattn_kv_pack for the same (Bc, H, S, d);
+ *   region_ids  : uint16 [Bw, L] - index of each table row into region_rows, or NULL for no bias;
+ *   region_rows : fp32 [n_rows, S] - the DISTINCT rows of the dense table (n_rows <= 32; the reference's tables have
+ *                 at most 2^regions distinct rows, encode_region_map_function.py:49-69).
+ * The forward kernel DMAs the image into LDS (global_load_lds) and folds sigma * std into an LDS bias table once per
+ * workgroup.  Flags: DSC_FLAG_REF_FP16_ROUNDING, DSC_FLAG_REUSE_STATS.  Workspace as dsc_region_xattn_workspace_bytes().
+ */
+size_t dsc_xattn_kv_pack_bytes(int Bc, int H, int S, int d);
+int dsc_xattn_kv_pack(const void* k, const void* v, void* packed, int Bc, int H, int S, int d,
+                      const int64_t k_strides[3], const int64_t v_strides[3], int dtype, void* stream);
+int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv, void* out,
+                                const uint16_t* region_ids, const float* region_rows, int n_rows,
+                                int Bc, int H, int L, int S, int d, int Bw, int n_std_groups,
+                                const int64_t q_strides[3], const int64_t o_strides[3],
+                                float sigma_host, const float* sigma_dev, float scale,
+                                int dtype, unsigned flags,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Flash self-attention forward - replaces `F.scaled_dot_product_attention(query, key, value)` on the self-attention

@@ -171,3 +171,44 @@ def test_std_couples_rows(ops):
     assert (o1[0].float() - o2[0].float()).abs().max().item() > 1e-2
     s1, s2 = ops.region_xattn(q, k, v, w, 0.7, n_std_groups=2), ops.region_xattn(q2, k, v, w, 0.7, n_std_groups=2)
     assert torch.equal(s1[0], s2[0])
+
+
+PACKED_SHAPES = [(2, 8, 4096, 77, 40, 2, 1), (2, 8, 1024, 77, 80, 2, 1), (2, 8, 256, 77, 160, 2, 1), (2, 8, 64, 77, 160, 2, 1),
+                 (4, 8, 256, 77, 80, 4, 2), (2, 10, 512, 77, 64, 2, 1), (2, 2, 32, 96, 8, 4, 1), (3, 5, 70, 1, 16, 3, 3),
+                 (2, 8, 100, 50, 40, 1, 1), (16, 8, 1024, 77, 40, 2, 8)]
+
+
+@pytest.mark.parametrize("Bc,H,L,S,d,Bw,ng", PACKED_SHAPES)
+def test_packed_path_equals_generic_and_oracle(ops, Bc, H, L, S, d, Bw, ng):
+    """pre-packed K/V + compressed region table: bit-identical to the generic kernel (same arithmetic, same order),
+    hence within the same tolerance of the oracle"""
+    x = attn_inputs(f"packed/{Bc}/{H}/{L}/{S}/{d}", Bc=Bc, H=H, L=L, S=S, d=d, Bw=Bw)
+    q, k, v, w = (torch.from_numpy(x[n]) for n in ("q", "k", "v", "w"))
+    qd, kd, vd = q.cuda().half(), k.cuda().half(), v.cuda().half()
+    gen = ops.region_xattn(qd, kd, vd, w.cuda(), 2.0, n_std_groups=ng)
+    packed = ops.xattn_kv_pack(kd, vd, layout="bhld")
+    comp = ops.compress_region_table(w.cuda())
+    assert comp is not None and comp[1].shape[0] <= 32
+    ids, rows = comp
+    assert torch.equal(rows[ids.long()].reshape(w.shape), w.cuda())          # lossless
+    q_blhd = qd.transpose(1, 2)                                              # [Bc, L, H, d] strided view
+    out = ops.region_xattn_packed(q_blhd, packed, S, (ids, rows), 2.0, n_std_groups=ng)
+    assert torch.equal(out.transpose(1, 2), gen)
+    exp = ra.region_attention(q, k, v, w, 2.0, n_std_groups=ng, fp16_rounding=True)
+    err = (out.transpose(1, 2).float().cpu() - exp).abs()
+    assert err.max().item() < tol16(q, k, w, 2.0, ng)
+    # fp32-score (lean) variant of both kernels: same result up to fp32 rounding of the exp2 / normalisation order
+    lean_p = ops.region_xattn_packed(q_blhd, packed, S, (ids, rows), 2.0, n_std_groups=ng, ref_fp16_rounding=False)
+    lean_g = ops.region_xattn(qd, kd, vd, w.cuda(), 2.0, n_std_groups=ng, ref_fp16_rounding=False)
+    assert (lean_p.transpose(1, 2).float() - lean_g.float()).abs().max().item() < 1e-3   # (w*sigma)*std*log2e groups differently
+    exp32 = ra.region_attention(q, k, v, w, 2.0, n_std_groups=ng)
+    assert (lean_g.float().cpu() - exp32).abs().max().item() < ATOL32
+    # no region: plain cross-attention through the packed image
+    out0 = ops.region_xattn_packed(q_blhd, packed, S, None, ref_fp16_rounding=False)
+    gen0 = ops.region_xattn(qd, kd, vd, None, ref_fp16_rounding=False)
+    assert torch.equal(out0.transpose(1, 2), gen0)
+
+
+def test_compress_region_table_refuses_dense_tables(ops):
+    w = torch.randn(2, 64, 77).cuda()
+    assert ops.compress_region_table(w) is None

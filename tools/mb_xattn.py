@@ -35,6 +35,16 @@ if which == "xattn":
         alg = Bc * (2 * (2 * L * C + 2 * S * C) + 4 * L * S)
         t_exit = tm_graph(lambda: f(region=None, debug_flags=8)); t_pro = tm_graph(lambda: f(region=None, debug_flags=16))
         print(f"   probes: exit-at-start {t_exit:.2f} us, prologue-only {t_pro:.2f} us")
+        packed = ops.xattn_kv_pack(k4, v4); comp = ops.compress_region_table(w)
+        fp = lambda **kw: ops.region_xattn_packed(q4, packed, S, kw.pop("region", comp), sig, n_std_groups=ng, out=out, **kw)
+        fp()
+        tp_pair = tm_graph(lambda: fp()); tp_fwd = tm_graph(lambda: fp(reuse_stats=True)); tp_nob = tm_graph(lambda: fp(region=None))
+        tl_pair = tm_graph(lambda: fp(ref_fp16_rounding=False)); tl_fwd = tm_graph(lambda: fp(ref_fp16_rounding=False, reuse_stats=True)); tl_nob = tm_graph(lambda: fp(region=None, ref_fp16_rounding=False))
+        for fl, nm in ((64, "tpw2"), (128, "tpw4")):
+            tt = tm_graph(lambda: fp(ref_fp16_rounding=False, reuse_stats=True, debug_flags=fl))
+            print(f"   PACKED fp32-score {nm}: fwd {tt:6.2f} us")
+        print(f"   PACKED fp32-score: stats+fwd {tl_pair:6.2f} us  fwd {tl_fwd:6.2f} us ({alg/tl_fwd/1e3:6.0f} GB/s alg)  fwd(no bias) {tl_nob:6.2f} us")
+        print(f"   PACKED: stats+fwd {tp_pair:6.2f} us  fwd {tp_fwd:6.2f} us ({alg/tp_fwd/1e3:6.0f} GB/s alg)  fwd(no bias) {tp_nob:6.2f} us")
         print(f"Bc{Bc} L{L} d{d}: stats+fwd {t_pair:6.2f} us ({alg/t_pair/1e3:6.0f} GB/s)  fwd(bias final, no std) {t_final:6.2f}  fwd(no bias) {t_nobias:6.2f} us", flush=True)
 else:
     for (B, H, L, d) in [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160)]:
