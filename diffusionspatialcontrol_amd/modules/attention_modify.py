@@ -122,16 +122,19 @@ def _sigma_arg(sigma, device):
     return s32
 
 
-def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None):
-    w_dev = resident_table(w, q.device)
+def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None,
+                      comp=None):
     if weight_func is None or weight_func_is_default(weight_func):
         if packed_kv is not None and layout == "blhd":
-            comp = compressed_table(w, q.device)
+            if comp is None:
+                comp = compressed_table(w, q.device)
             if comp is not None:                 # prepared operands: packed text K/V + row-id region table
                 return ops.region_xattn_packed(q, packed_kv, k.shape[1], comp, _sigma_arg(sigma, q.device),
                                                n_std_groups=n_std_groups, scale=scale, ref_fp16_rounding=ref16)
+        w_dev = resident_table(w, q.device)
         return ops.region_xattn(q, k, v, w_dev, _sigma_arg(sigma, q.device), layout=layout, n_std_groups=n_std_groups,
                                 scale=scale, ref_fp16_rounding=ref16)
+    w_dev = resident_table(w, q.device)
     # generic weight_func: evaluate it the way the reference does (attention_modify.py:90-95), then let the kernel
     # add its result (flag BIAS_IS_FINAL).  Slow path by construction - the scores are materialised once.
     qh, kh = (q, k) if layout == "bhld" else (q.transpose(1, 2), k.transpose(1, 2))
@@ -223,8 +226,10 @@ class _RegionProcessor:
         if is_xattn and isinstance(region_prompt["region_state"], dict):
             w = region_prompt["region_state"][img_sequence_length]          # KeyError when L is not a level (:481)
             groups = region_prompt.get("n_std_groups", self.n_std_groups)
+            pre = region_prompt.get("compressed")                           # the pipeline's static (ids, rows) buffers
+            comp = pre.get(img_sequence_length) if isinstance(pre, dict) else None
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
-                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv)
+                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp)
         elif not is_self:
             if packed_kv is not None:
                 out = ops.region_xattn_packed(q4, packed_kv, S, None, scale=sc, ref_fp16_rounding=False)

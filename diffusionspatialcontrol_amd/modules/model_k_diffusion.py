@@ -22,6 +22,7 @@ external_k_diffusion.py:109-114 broadcasts c_in[B] against input[2B]).
 """
 import importlib
 import inspect
+import os
 import time
 from typing import List, Optional, Union
 
@@ -238,11 +239,15 @@ class StableDiffusionPipeline:
 
     # ---- fused mode
     def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs):
-        """Static buffers + the captured UNet step for this (shape, region tables, text) combination."""
+        """Static buffers + the captured UNet step.  The graph is keyed by SHAPES only: a new generation with other
+        text / other region masks updates the static buffers in place (text, its packed K/V, the compressed region
+        tables) and replays the same graph."""
         st = self._graphs.get(key)
-        if st is not None:
+        comp_cpu = self._compress_tables(region_state)
+        if st is not None and (st["compressed"] is None) == (comp_cpu is None):
             st["text"].copy_(text)
             self._refresh_text_kv(st["text"])
+            self._upload_tables(st, comp_cpu, region_state)
             return st
         dev, dt = text.device, text.dtype
         rows = 2 * n_img
@@ -251,11 +256,14 @@ class StableDiffusionPipeline:
             "t": torch.zeros(rows, device=dev, dtype=torch.float32),
             "sigma": torch.ones(1, device=dev, dtype=torch.float32),
             "text": text.clone(),
+            "compressed": None, "region_state": region_state,
         }
+        if comp_cpu is not None:
+            st["compressed"] = {L: (ids.to(dev), rws.to(dev)) for L, (ids, rws) in comp_cpu.items()}
         self._refresh_text_kv(st["text"])
         kw = dict(cross_attention_kwargs)
-        kw["region_prompt"] = {"region_state": region_state, "sigma": st["sigma"], "weight_func": weight_func,
-                               "n_std_groups": n_img}
+        kw["region_prompt"] = {"region_state": region_state, "compressed": st["compressed"], "sigma": st["sigma"],
+                               "weight_func": weight_func, "n_std_groups": n_img}
 
         def step():
             return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw).sample
@@ -263,7 +271,7 @@ class StableDiffusionPipeline:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(2):                   # warm-up: table upload, workspaces, MIOpen/hipBLASLt algo selection
+            for _ in range(2):                   # warm-up: workspaces, MIOpen / hipBLASLt kernel selection
                 st["eps"] = step()
         torch.cuda.current_stream(dev).wait_stream(side)
         if not ops.GRAPHS_ENABLED:
@@ -274,8 +282,31 @@ class StableDiffusionPipeline:
                 st["eps"] = step()
             st["graph"] = g
             st["run"] = g.replay
-        self._graphs = {key: st}                 # keep one: the tables/text of the previous generation are dead
+        self._graphs = {key: st}                 # keep one
         return st
+
+    @staticmethod
+    def _compress_tables(region_state):
+        """{L: (ids, rows padded to 32)} on the CPU, or None when there is no table / a level is not compressible
+        (then the dense tables are used and the graph is re-captured per generation)."""
+        if not isinstance(region_state, dict) or not region_state:
+            return None
+        out = {}
+        for L, w in region_state.items():
+            c = ops.compress_region_table(w.float().cpu() if w.is_cuda else w.float(), pad_rows=True)
+            if c is None:
+                return None
+            out[L] = c
+        return out
+
+    @staticmethod
+    def _upload_tables(st, comp_cpu, region_state):
+        if comp_cpu is None:
+            return
+        for L, (ids, rws) in comp_cpu.items():
+            dst_ids, dst_rows = st["compressed"][L]
+            dst_ids.copy_(ids, non_blocking=True)
+            dst_rows.copy_(rws, non_blocking=True)
 
     def _refresh_text_kv(self, text):
         """K/V projections of the text for every cross-attention layer, once per generation (they are step-invariant;
@@ -306,14 +337,23 @@ class StableDiffusionPipeline:
 
     def _denoise_fused(self, latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                        cross_attention_kwargs, start_time, timeout):
+        prof = os.environ.get("DSC_PROFILE_HOST") == "1"
+        if prof:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         kdm = self.k_diffusion_model
         sig = sigmas.detach().float().cpu().tolist()                 # the only device->host transfer, before the loop
         coeffs = sampling.dpmpp_2m_coefficients(sig)
-        key = (n_img, tuple(latents.shape), id(region_state) if isinstance(region_state, dict) else None,
-               tuple(text.shape), text.dtype)
+        levels = tuple(sorted((int(L), tuple(w.shape)) for L, w in region_state.items())) \
+            if isinstance(region_state, dict) else None
+        key = (n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
+               if hasattr(weight_func, "__code__") else id(weight_func))
         st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs)
         x = latents.contiguous().clone()
         old = torch.zeros_like(x)
+        if prof:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
         c_in, _, t = kdm.step_scalars(sig[0])
         ops.prepare_unet_input(x, c_in, t, sig[0], st["x_in"], st["t"], st["sigma"])
         for i, (a, b, c) in enumerate(coeffs):
@@ -325,4 +365,9 @@ class StableDiffusionPipeline:
             # x <- a*x + b*D + c*D_old with D = x - sigma*(eps_u + g*(eps_c - eps_u)); also writes next x_in/t/sigma
             ops.cfg_dpmpp2m_step(x, st["eps"], old, sig[i], guidance_scale, a, b, c, c_in_n, t_n, max(nxt, 1e-10),
                                  st["x_in"], st["t"], st["sigma"])
+        if prof:
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            print(f"[dsc host profile] setup (tables, text K/V, graph) {1e3 * (t1 - t0):.1f} ms, "
+                  f"{len(coeffs)}-step loop {1e3 * (t2 - t1):.1f} ms", flush=True)
         return x

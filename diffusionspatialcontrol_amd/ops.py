@@ -2,6 +2,7 @@
 the current HIP stream and strides; all arithmetic happens in libdsc_hip.so."""
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -121,13 +122,34 @@ def xattn_kv_pack(k, v, *, layout="blhd", out=None):
 MAX_REGION_ROWS = 32
 
 
-def compress_region_table(w):
-    """dense fp32 [Bw, L, S] -> (ids uint16 [Bw, L], rows fp32 [NU, S]) with rows = the distinct table rows, or None
-    when there are more than MAX_REGION_ROWS of them.  Host/torch work, once per table (lossless: ids index rows)."""
+def compress_region_table(w, pad_rows=False):
+    """dense fp32 [Bw, L, S] -> (ids int16 [Bw, L], rows fp32 [NU, S]) with rows = the distinct table rows, or None
+    when there are more than MAX_REGION_ROWS of them.  Lossless (rows[ids] == w).  Works on the tensor's own device:
+    on a CPU table (where the reference keeps them, encode_region_map_function.py:33-34) nothing touches the GPU.
+    pad_rows: zero-pad `rows` to MAX_REGION_ROWS so that shapes (and captured kernel arguments) never change."""
     Bw, L, S = w.shape
-    rows, inv = torch.unique(w.reshape(Bw * L, S), dim=0, return_inverse=True)
-    if rows.shape[0] > MAX_REGION_ROWS:
-        return None
+    flat = w.reshape(Bw * L, S)
+    if not flat.is_cuda:
+        # numpy (single-threaded, no torch intra-op pool): distinct rows through a 1-D key (two fixed random
+        # projections in fp64), then verified exactly
+        a = flat.contiguous().numpy()
+        proj = np.random.default_rng(1234).random((S, 2))
+        key = a.astype(np.float64) @ proj
+        _, first_idx, inv_np = np.unique(key[:, 0] * 1.000123 + key[:, 1], return_index=True, return_inverse=True)
+        if first_idx.shape[0] > MAX_REGION_ROWS:
+            return None
+        rows_np = a[first_idx]
+        if not np.array_equal(rows_np[inv_np], a):       # projection collision (never seen): exact fallback
+            rows_np, inv_np = np.unique(a, axis=0, return_inverse=True)
+            if rows_np.shape[0] > MAX_REGION_ROWS:
+                return None
+        rows, inv = torch.from_numpy(np.ascontiguousarray(rows_np)), torch.from_numpy(inv_np.reshape(-1).astype(np.int64))
+    else:
+        rows, inv = torch.unique(flat, dim=0, return_inverse=True)
+        if rows.shape[0] > MAX_REGION_ROWS:
+            return None
+    if pad_rows and rows.shape[0] < MAX_REGION_ROWS:
+        rows = torch.cat([rows, rows.new_zeros(MAX_REGION_ROWS - rows.shape[0], S)])
     return inv.reshape(Bw, L).to(torch.int16).contiguous(), rows.contiguous()
 
 
