@@ -14,10 +14,12 @@ seeded text embeddings, rectangular 64-px-aligned region masks.  
 the timed region starts; the final latents stay on the device (VAE decode is outside the path).
 
 Extra objects on the JSON line:
-  roofline     - the region cross-attention forward kernel (`xattn_fwd`, L=4096 level of the same workload) timed
-                 live with HIP events on its own stream: algorithmic bytes per launch / average launch duration vs the
-                 8 TB/s HBM peak.  Algorithmic bytes per launch = 6.60 MB per UNet row (BASELINE.md section 3:
-                 2*(2*L*C + 2*S*C) + 4*L*S at L=4096, C=320, S=77) x Bc rows.
+  roofline     - the region cross-attention forward kernel (`xp_fwd`, L=4096 level of the same workload) timed live with
+                 HIP events around graph-captured back-to-back launches on the stream they run on: algorithmic bytes
+                 per launch / average launch duration vs the 8 TB/s HBM peak.  Algorithmic bytes per launch = 6.60 MB
+                 per UNet row (2*(2*L*C + 2*S*C) + 4*L*S at L=4096, C=320, S=77) x Bc rows.
+  roofline_self_attn - the flash self-attention kernel at the same level against the 2.5 PFLOP/s dense fp16 MFMA peak
+                 (4*L^2*C FLOPs per row).
   cpu_baseline - the oracle (oracle/unet_ref.py, torch fp32, op-for-op unfused like the reference) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -49,7 +51,7 @@ def parse():
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
                          "falls back to kernels >10x slower on this image; off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=1)
+    ap.add_argument("--cpu-sample-steps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -77,22 +79,36 @@ def synthetic_inputs(size, regions, S=77, ctx=768):
     return emb, [pos.copy(), pos], state, tok
 
 
-def hip_event_time_ms(fn, iters, stream):
-    """average duration of fn() launched `iters` times on `stream`, measured with HIP events on that stream"""
-    with torch.cuda.stream(stream):
-        for _ in range(5):
+def graph_launch_time_us(fn, launches=50, replays=10):
+    """Average duration of ONE launch of fn(): `launches` back-to-back launches are captured into a HIP graph (so the
+    host's ~10 us ctypes/launch overhead is out of the picture), the graph is replayed `replays` times and timed with HIP
+    events recorded on the stream the replays run on (torch's current stream)."""
+    dev = torch.cuda.current_device()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
             fn()
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record(stream)
-        for _ in range(iters):
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(launches):
             fn()
-        end.record(stream)
+    g.replay()
+    torch.cuda.synchronize(dev)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(replays):
+        g.replay()
+    end.record()
     end.synchronize()
-    return start.elapsed_time(end) / iters
+    return start.elapsed_time(end) / (launches * replays) * 1e3
 
 
 def roofline_region_xattn(dev, n_img):
-    """the region cross-attention forward kernel at the L=4096 level (C=320, H=8, d=40, S=77), Bc = 2*n_img rows"""
+    """The region cross-attention forward kernel (`xp_fwd`, prepared-operand path the pipeline runs) at the L=4096 level
+    of the workload (C=320, H=8, d=40, S=77), Bc = 2*n_img rows.  HBM-bound by arithmetic intensity (61 FLOP/B)."""
     from diffusionspatialcontrol_amd import ops
     Bc, H, L, S, d = 2 * n_img, 8, 4096, 77, 40
     C = H * d
@@ -102,32 +118,51 @@ def roofline_region_xattn(dev, n_img):
     v = torch.randn(Bc, S, C, generator=g).half().to(dev)
     w = torch.zeros(2, L, S)
     w[:, 1000:2000, 2:4] = 0.5
-    w = w.to(dev)
+    w[:, 2500:3500, 4:6] = 0.5
     sig = torch.tensor([7.0], device=dev)
     out = torch.empty(Bc, L, H, d, dtype=torch.half, device=dev)
     q4, k4, v4 = q.view(Bc, L, H, d), k.view(Bc, S, H, d), v.view(Bc, S, H, d)
-    st = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(st):
-        ops.region_xattn(q4, k4, v4, w, sig, layout="blhd", n_std_groups=n_img, out=out)   # fills the partials
-    st.synchronize()
-    pair = hip_event_time_ms(lambda: ops.region_xattn(q4, k4, v4, w, sig, layout="blhd", n_std_groups=n_img, out=out),
-                             200, st)
-    fwd = hip_event_time_ms(lambda: ops.region_xattn(q4, k4, v4, w, sig, layout="blhd", n_std_groups=n_img, out=out,
-                                                     reuse_stats=True), 200, st)
+    packed = ops.xattn_kv_pack(k4, v4)
+    ids, rows = ops.compress_region_table(w, pad_rows=True)
+    comp = (ids.to(dev), rows.to(dev))
+    call = lambda **kw: ops.region_xattn_packed(q4, packed, S, comp, sig, n_std_groups=n_img, out=out,  # noqa: E731
+                                                ref_fp16_rounding=False, **kw)
+    call()                                                              # leaves the std partials in the workspace
+    pair = graph_launch_time_us(lambda: call())
+    fwd = graph_launch_time_us(lambda: call(reuse_stats=True))
     alg_bytes = Bc * (2 * (2 * L * C + 2 * S * C) + 4 * L * S)
-    achieved = alg_bytes / (fwd * 1e-3) / 1e9
+    achieved = alg_bytes / (fwd * 1e-6) / 1e9
     traffic = None
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pj):
         try:
-            traffic = json.load(open(pj)).get("xattn_fwd_hbm_bytes_per_launch")
+            traffic = json.load(open(pj)).get("xp_fwd_hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             traffic = None
-    return {"kernel": "xattn_fwd<3,true> (region cross-attention forward, L=4096 C=320 S=77, Bc=%d)" % Bc,
+    return {"kernel": "xp_fwd<3,false> (region cross-attention forward, L=4096 C=320 S=77, Bc=%d)" % Bc,
             "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd * 1e3, 2),
-            "stats_plus_fwd_us": round(pair * 1e3, 2)}
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd, 2),
+            "stats_plus_fwd_us": round(pair, 2),
+            "note": "algorithmic bytes = SURVEY.md 8d per-row figure (6.60 MB incl. the dense fp32 table) x Bc rows; the kernel "
+                    "itself reads the table as uint16 row ids + <=32 distinct rows"}
+
+
+def roofline_self_attn(dev, n_img):
+    """The flash self-attention kernel at the L=4096 level (C=320, H=8, d=40): MFMA-bound (AI = L/2 = 2048 FLOP/B)."""
+    from diffusionspatialcontrol_amd import ops
+    Bc, H, L, d = 2 * n_img, 8, 4096, 40
+    C = H * d
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(Bc, L, 3 * C, generator=g).half().to(dev)
+    q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+    out = torch.empty(Bc, L, H, d, dtype=torch.half, device=dev)
+    us = graph_launch_time_us(lambda: ops.self_attention(q, k, v, out=out), launches=20, replays=5)
+    flops = 4.0 * L * L * C * Bc
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": "self_attn_fwd<3,4> (flash self-attention, L=4096 C=320 d=40, Bc=%d)" % Bc, "bound": "mfma",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2)}
 
 
 def host_cores():
@@ -240,6 +275,7 @@ def main():
                        "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite},
         }
         res["roofline"] = roofline_region_xattn(dev, n_img)
+        res["roofline_self_attn"] = roofline_self_attn(dev, n_img)
         if world == 1 and not a.no_cpu_baseline:
             from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
             rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)
