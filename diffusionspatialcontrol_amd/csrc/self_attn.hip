@@ -49,11 +49,17 @@ __device__ __forceinline__ h4_t tr_read(const half_t* p) {
     return __builtin_bit_cast(h4_t, r);
 }
 
-template <int NK, int WAVES>
+// QT query tiles (32 rows each) per wave share every K fragment read and every V^T transposed read.
+// ONES (NK odd: the PV row tile has >= 16 padding channels): V's first padding column holds 1.0, so the PV MFMA
+// returns sum_s p[s] in output channel 16*NK for free - no per-score adds, and the sum uses the same fp16-rounded p as
+// the numerator.
+template <int NK, int WAVES, int QT>
 __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
     using C = SaCfg<NK>;
     constexpr int T = 64 * WAVES, DM = C::DM, KP = C::KP, VP = C::VP;
     constexpr int CH = (kKV * 2 * NK + T - 1) / T;          // 16-byte chunks per thread per operand per tile
+    constexpr bool ONES = (NK & 1) != 0;
+    constexpr float kTau = 8.f;                              // lazy rescale: p <= 2^8, exact enough in fp16 / fp32 sums
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* lds = reinterpret_cast<half_t*>(smem);
 
@@ -64,13 +70,13 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         else { bh = bid % nbh; qb = bid / nbh; }
     }
     const int b = bh / p.H, h = bh % p.H;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
-    const int q0 = (qb * WAVES + wave) * 32;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+    const int q0 = (qb * WAVES + wave) * 32 * QT;
     const int d8 = p.d >> 3;
     const half_t* kg = p.k + b * p.ksb + h * p.ksh;
     const half_t* vg = p.v + b * p.vsb + h * p.vsh;
 
-    // zero the K pad columns [d, 16*NK) of both buffers once (the staging never writes them)
+    // one-time LDS constants of both buffers: zero K pad columns [d, 16*NK); V ones column 16*NK (ONES)
     if (16 * NK > p.d) {
         const int padc = 16 * NK - p.d;
         for (int idx = threadIdx.x; idx < 2 * kKV * padc; idx += T) {
@@ -78,18 +84,23 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
             lds[buf * C::TILE_HALVES + (rem / padc) * KP + p.d + rem % padc] = (half_t)0;
         }
     }
+    if (ONES) {
+        for (int idx = threadIdx.x; idx < 2 * kKV; idx += T)
+            lds[(idx / kKV) * C::TILE_HALVES + kKV * KP + (idx % kKV) * VP + 16 * NK] = (half_t)1;
+    }
 
-    // Q^T fragments stay in registers: qf[ks] = Q[q0 + r][16 ks + 8 hh .. +8]
-    h8_t qf[NK];
-    {
-        const int row = min(q0 + r, p.L - 1);
+    // Q^T fragments stay in registers: qf[qt][ks] = Q[q0 + 32 qt + r][16 ks + 8 hh .. +8]
+    h8_t qf[QT][NK];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int row = min(q0 + 32 * qt + r, p.L - 1);
         const half_t* qp = p.q + b * p.qsb + h * p.qsh + (long long)row * p.qsl;
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             const int col = 16 * ks + 8 * hh;
             h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
             if (col < p.d) val = *reinterpret_cast<const h8_t*>(qp + col);
-            qf[ks] = val;
+            qf[qt][ks] = val;
         }
     }
 
@@ -120,12 +131,17 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         }
     };
 
-    f16x_t o[DM];
+    f16x_t o[QT][DM];
+    float m_run[QT], l_run[QT];
 #pragma unroll
-    for (int dm = 0; dm < DM; ++dm)
+    for (int qt = 0; qt < QT; ++qt) {
+        m_run[qt] = -INFINITY;
+        l_run[qt] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[dm][i] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[qt][dm][i] = 0.f;
+    }
 
     const int ntiles = (p.S + kKV - 1) / kKV;
     stage_load(0);
@@ -134,6 +150,7 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
 
     // per-lane constant part of the transposed-read address: row (4 hh + (i >> 2)), column 16 * ((lane >> 4) & 1) + 4 * (i & 3)
     const int tr_off = (4 * hh + ((lane & 15) >> 2)) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const float c2 = p.scale_log2e;
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
@@ -141,51 +158,69 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         const half_t* Kb = lds + buf * C::TILE_HALVES;
         const half_t* Vb = Kb + kKV * KP;
 
-        // ---- S^T = K . Q^T  (2 row tiles of 32 keys)
-        f16x_t s[2];
+        // ---- S^T = K . Q^T  (2 row tiles of 32 keys); each K fragment feeds the QT query tiles
+        f16x_t s[QT][2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[m][i] = 0.f;
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[qt][m][i] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 const h8_t kf = *reinterpret_cast<const h8_t*>(Kb + (32 * m + r) * KP + 16 * ks + 8 * hh);
-                s[m] = mfma_32x32x16(kf, qf[ks], s[m]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[qt][m] = mfma_32x32x16(kf, qf[qt][ks], s[qt][m]);
             }
-        }
-        // ---- online softmax (base-2): element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this tile
-        const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float a = s[m][i] * p.scale_log2e;
-                if (kv_left < kKV && 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh >= kv_left) a = -INFINITY;
-                s[m][i] = a;
-                mx = fmaxf(mx, a);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        float psum = 0.f;
-        h8_t pf[4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(s[m][i] - m_new);
-                psum += e;
-                pf[2 * m + (i >> 3)][i & 7] = (half_t)e;
-            }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;
 
-        // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels)
+        // ---- online softmax, base 2, lazy rescale.  Element i of s[qt][m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh.
+        const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
+        h8_t pf[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            if (kv_left < kKV) {                             // wave-uniform: only the ragged last tile masks
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh >= kv_left) s[qt][m][i] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s[qt][m][i], s[qt][m][i + 1]));   // v_max3_f32
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;     // c2 > 0: max commutes with the scaling
+            if (__any(mx > m_run[qt] + kTau)) {              // wave-uniform: some row's max grew by more than 2^tau
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[qt][dm][i] *= alpha;
+            }
+            const float nm = -m_run[qt];
+            float psum = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][m][i], c2, nm));
+                    if (!ONES) psum += e;
+                    s[qt][m][i] = e;
+                }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) pf[qt][2 * m + (i >> 3)][i & 7] = (half_t)s[qt][m][i];
+            if (!ONES) l_run[qt] += psum;
+        }
+
+        // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels); V^T fragments shared by the QT tiles
 #pragma unroll
         for (int dm = 0; dm < DM; ++dm) {
 #pragma unroll
@@ -194,7 +229,8 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
                 const h4_t lo = tr_read(vp);
                 const h4_t hi = tr_read(vp + 8 * VP);
                 const h8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[dm] = mfma_32x32x16(vf, pf[tt], o[dm]);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[qt][dm] = mfma_32x32x16(vf, pf[qt][tt], o[qt][dm]);
             }
         }
         if (t + 1 < ntiles) stage_write(buf ^ 1);            // buffer buf^1 was last read in iteration t-1
@@ -202,54 +238,75 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
     }
 
     // ---- epilogue: O / l, fp16, out[b, q, h, :]
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    if (q0 + r < p.L) {
-        half_t* op = p.out + b * p.osb + h * p.osh + (long long)(q0 + r) * p.osl;
 #pragma unroll
-        for (int dm = 0; dm < DM; ++dm)
+    for (int qt = 0; qt < QT; ++qt) {
+        float l_tot;
+        if (ONES) {
+            // channel 16*NK of O^T is sum_s p: row tile DM-1, element 8 * ((16 NK - 32 (DM-1)) >> 3) of the hh = 0 lanes
+            constexpr int kIdx = 4 * ((16 * NK - 32 * (DM - 1)) >> 3);
+            const float mine = o[qt][DM - 1][kIdx];
+            l_tot = __shfl(mine, r, 64);                     // lane r (hh = 0) holds it for query row r
+        } else {
+            l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);
+        }
+        const float inv = 1.f / l_tot;
+        const int qrow = q0 + 32 * qt + r;
+        if (qrow < p.L) {
+            half_t* op = p.out + b * p.osb + h * p.osh + (long long)qrow * p.osl;
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
-                if (dd0 < p.d) {
-                    const h4_t ov = {(half_t)(o[dm][4 * g4] * inv), (half_t)(o[dm][4 * g4 + 1] * inv),
-                                     (half_t)(o[dm][4 * g4 + 2] * inv), (half_t)(o[dm][4 * g4 + 3] * inv)};
-                    *reinterpret_cast<h4_t*>(op + dd0) = ov;
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                    if (dd0 < p.d) {
+                        const h4_t ov = {(half_t)(o[qt][dm][4 * g4] * inv), (half_t)(o[qt][dm][4 * g4 + 1] * inv),
+                                         (half_t)(o[qt][dm][4 * g4 + 2] * inv), (half_t)(o[qt][dm][4 * g4 + 3] * inv)};
+                        *reinterpret_cast<h4_t*>(op + dd0) = ov;
+                    }
                 }
-            }
+        }
     }
 }
 
-template <int NK, int WAVES>
+template <int NK, int WAVES, int QT>
 int launch(const SaParams& p0, hipStream_t st) {
     SaParams p = p0;
-    p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
+    p.nqb = (p.L + 32 * QT * WAVES - 1) / (32 * QT * WAVES);
     p.xcd_map = ((p.Bc * p.H) % 8 == 0) ? 1 : 0;
     const size_t lds = (size_t)2 * SaCfg<NK>::TILE_HALVES * sizeof(half_t);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, QT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((self_attn_fwd<NK, WAVES>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
+    hipLaunchKernelGGL((self_attn_fwd<NK, WAVES, QT>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
+
+int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant): 0 = auto
 
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
     // enough workgroups to fill 256 CUs: 4 waves (128 query rows) per workgroup when that still gives >= 256 of them
     const long long wg4 = (long long)p.Bc * p.H * ((p.L + 127) / 128);
-    if (wg4 >= 256) return launch<NK, 4>(p, st);
+    if (NK <= 4) {
+        const long long wg4x2 = (long long)p.Bc * p.H * ((p.L + 255) / 256);
+        (void)wg4x2;    // measured: two query tiles per wave lose to one (220+ VGPRs -> 1 wave/SIMD): tuning variant only
+        if (g_sa_variant == 2) return launch<NK, 4, (NK <= 4 ? 2 : 1)>(p, st);
+    }
+    if (wg4 >= 256 || g_sa_variant == 1) return launch<NK, 4, 1>(p, st);
     const long long wg2 = (long long)p.Bc * p.H * ((p.L + 63) / 64);
-    if (wg2 >= 128 || NK >= 6) return launch<NK, 2>(p, st);   // one wave alone would need 160 staging registers at d = 160
-    return launch<NK, (NK >= 6 ? 2 : 1)>(p, st);
+    if (wg2 >= 128 || NK >= 6) return launch<NK, 2, 1>(p, st);   // one wave alone would need 160 staging registers at d = 160
+    return launch<NK, (NK >= 6 ? 2 : 1), 1>(p, st);
 }
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 bool strides_ok(const int64_t s[3]) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s[2] % 8 == 0; }
 
 }  // namespace
+
+extern "C" void dsc_debug_set_self_attn_variant(int v) { g_sa_variant = v; }
 
 extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, void* out, int Bc, int H, int L, int S,
                                  int d, const int64_t q_strides[3], const int64_t k_strides[3],

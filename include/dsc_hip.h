@@ -48,6 +48,9 @@ const char* dsc_target_arch(void);
 /* Diagnostic builds only: a 2-KiB device buffer that receives in-kernel clock stamps of workgroup 0 when a
  * call carries debug flag 32 (tools/mb_xattn.py); NULL (default) disables it.  No output tensor is ever touched. */
 void dsc_debug_set_stamp_buffer(void* device_buffer_2KiB);
+/* Tuning aid: force a tiling variant of the flash self-attention kernel (0 = automatic choice, 1 = one query tile per
+ * wave, 2 = two query tiles per wave where the head dim allows it). */
+void dsc_debug_set_self_attn_variant(int variant);
 /* Human-readable text for a status code. */
 const char* dsc_status_string(int status);
 

@@ -1,0 +1,32 @@
+"""microbench: flash self-attention variants (graph-captured launches)"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusionspatialcontrol_amd import ops, _lib
+lib = _lib.load_library()
+dev = "cuda"
+def tm_graph(fn, n=20, reps=5):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3): fn()
+    st.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): g.replay()
+    e.record(); e.synchronize()
+    return s.elapsed_time(e) / (n * reps) * 1e3
+for (B, H, L, d) in [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160), (16, 8, 4096, 40), (2, 10, 4096, 64)]:
+    qkv = torch.randn(B, L, 3 * H * d, device=dev).half(); C = H * d
+    q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+    out = torch.empty(B, L, H, d, device=dev, dtype=torch.half)
+    res = []
+    for var in (1, 2, 0):
+        lib.dsc_debug_set_self_attn_variant(var)
+        t1 = tm_graph(lambda: ops.self_attention(q, k, v, out=out))
+        res.append(f"variant {var}: {t1:8.2f} us ({4.0*B*H*L*L*d/t1/1e6:6.0f} TF)")
+    lib.dsc_debug_set_self_attn_variant(0)
+    print(f"self-attn B{B} H{H} L{L} d{d}: " + "  ".join(res), flush=True)
