@@ -1,0 +1,212 @@
+// fp16 projection GEMM with fused epilogues for the UNet's token-major linears (dsc_linear_f16).
+//
+//   out[m, n] = sum_k x[m, k] * w[n, k]  (+ bias[n]) (+ residual[m, n])                      plain
+//   out[m, j] = (acc[m, j] + bias[j]) * gelu(acc[m, N/2 + j] + bias[N/2 + j])                 GEGLU (diffusers GEGLU)
+//
+// Replaces F.linear (+ the separate residual add / GEGLU kernels) for `to_q/to_k/to_v/to_out`, the feed-forward
+// linears and the 1x1 `proj_in/proj_out/conv_shortcut` of the UNet blocks that reference
+// `source/modules/u_net_condition_modify.py` takes from diffusers.  hipBLASLt serves these
+// shapes (M = 128..8192 tokens, K,N = 320..10240) at a ~12.5 us latency floor per call with ~110 calls per UNet step
+// (profiles/README.md); this kernel is sized for exactly that regime: few K iterations, latency first.
+//
+// MI355X mapping:
+//   * both operands are K-contiguous (activations [M,K], torch Linear weights [N,K]), the layout MFMA fragments want:
+//     D^T[n, m] = W[n, :] . X[m, :]  on v_mfma_f32_32x32x16_f16 (A = W rows, B = X^T), so a lane owns one token row m
+//     with 4 consecutive output channels per register group;
+//   * tiles (128 tokens x 64 channels x 64 K) go HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR staging); the
+//     LDS image is lane-linear, so the bank-conflict XOR swizzle (16-byte chunk ^= row & 7) is applied to the per-lane
+//     SOURCE address and again on the ds_read_b128 address (guide rule 21);
+//   * a ring of STAGES LDS buffers: STAGES-1 K tiles are in flight by DMA while one is multiplied; a counted
+//     `s_waitcnt vmcnt(6*(STAGES-2))` + a RAW s_barrier publish tile t without draining the younger DMAs
+//     (__syncthreads() would wait vmcnt(0)); the refill of a buffer is issued right after the barrier that proves every
+//     wave finished reading it (one barrier per K tile);
+//   * epilogue through LDS: accumulators (fp32) are transposed via an LDS stage so that bias / residual reads and the
+//     fp16 stores are full 128-byte row segments instead of 8-byte column-strided pieces; ONE fp16 rounding.
+#include "dsc_common.h"
+#include "dsc_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 64, T = 256;
+constexpr int kAHalves = BM * BK, kBHalves = BN * BK;       // one stage: A tile then B tile
+constexpr int kStage = kAHalves + kBHalves;                  // 12288 halves = 24 KiB
+constexpr int kEpiStride = BN + 4;                           // fp32 staging row stride: 68 dwords -> b128 writes conflict-free
+
+struct GemmParams {
+    const half_t* x; const half_t* w; const half_t* bias; const half_t* res; half_t* out;
+    int M, N, K;                 // N = rows of w (2x the output width for GEGLU)
+    long long ldx, ldr, ldo;     // row strides (elements) of x, residual, out
+};
+
+// DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^(row&7)
+template <int ROWS>
+__device__ __forceinline__ void dma_tile(const half_t* g, long long ld, int row0, int rows_valid, int k0, half_t* lds,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int pc = 0; pc < ROWS / 8 / 4; ++pc) {
+        const int piece = pc * 4 + wave;
+        const int row = piece * 8 + (lane >> 3);
+        const int grow = min(row0 + row, rows_valid - 1);
+        const int chunk = (lane & 7) ^ (row & 7);
+        const half_t* src = g + (long long)grow * ld + k0 + chunk * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(lds + piece * 512), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ h8_t lds_frag(const half_t* tile, int row, int kchunk) {
+    return *reinterpret_cast<const h8_t*>(tile + row * BK + ((kchunk ^ (row & 7)) << 3));
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// GEGLU: the workgroup's 64 weight rows are 32 "hidden" rows n0h.. and the 32 matching "gate" rows N/2 + n0h..
+template <bool GEGLU, int STAGES>
+__global__ __launch_bounds__(T, 2) void gemm_tn_f16(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* lds = reinterpret_cast<half_t*>(smem);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): 64 x 32 per wave
+    const int nb = GEGLU ? p.N / 64 : p.N / BN;              // column blocks (GEGLU: 32 output columns per block)
+    const int bid = blockIdx.x;
+    const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel (L2)
+    const int m0 = bm * BM;
+    const int n0 = GEGLU ? bn * 32 : bn * BN;
+    const int Nh = p.N / 2;
+
+    auto issue = [&](int kt, int buf) {
+        half_t* a = lds + buf * kStage;
+        dma_tile<BM>(p.x, p.ldx, m0, p.M, kt * BK, a, wave, lane);
+        if (GEGLU) {
+            // B tile rows 0..31 = w[n0 .. n0+32), rows 32..63 = w[Nh + n0 .. Nh + n0 + 32): two half-tiles of 4 pieces
+            half_t* b = a + kAHalves;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                const int piece = pc * 4 + wave;             // 8 pieces of 8 rows
+                const int row = piece * 8 + (lane >> 3);
+                const int grow = (row < 32 ? n0 + row : Nh + n0 + row - 32);
+                const int chunk = (lane & 7) ^ (row & 7);
+                const half_t* src = p.w + (long long)grow * p.K + kt * BK + chunk * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(b + piece * 512), 16, 0, 0);
+            }
+        } else {
+            dma_tile<BN>(p.w, p.K, n0, p.N, kt * BK, a + kAHalves, wave, lane);
+        }
+    };
+
+    f16x_t acc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (st < nk) issue(st, st);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt % STAGES;
+        // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (6 DMA instructions each) are outstanding
+        const int younger = min(STAGES - 2, nk - 1 - kt);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // raw: publishes tile kt, proves tile kt-1's reads are done
+        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        const half_t* a = lds + buf * kStage;
+        const half_t* b = a + kAHalves;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const h8_t wf = lds_frag(b, wn * 32 + r, 2 * ks + hh);                    // W[n][16 ks + 8 hh ..]
+            const h8_t x0 = lds_frag(a, wm * 64 + r, 2 * ks + hh);                    // X[m][...]
+            const h8_t x1 = lds_frag(a, wm * 64 + 32 + r, 2 * ks + hh);
+            acc[0] = mfma_32x32x16(wf, x0, acc[0]);
+            acc[1] = mfma_32x32x16(wf, x1, acc[1]);
+        }
+    }
+    __syncthreads();                                         // all MFMA operand reads done: LDS becomes the epilogue stage
+
+    // ---- epilogue stage: stage[m][n] fp32; acc[mt] element i <-> n = wn*32 + (i&3) + 8(i>>2) + 4hh, m = wm*64 + mt*32 + r
+    float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f4x_t v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+            *reinterpret_cast<f4x_t*>(stage + (wm * 64 + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = v;
+        }
+    __syncthreads();
+    if (GEGLU) {
+        // output tile 128 x 32: 4 chunks of 8 columns per row -> 512 chunks, 2 per thread
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int idx = threadIdx.x + c * T, row = idx >> 2, ch = idx & 3;
+            if (m0 + row < p.M) {
+                const float* sp = stage + row * kEpiStride + ch * 8;
+                const h8_t bh = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
+                const h8_t bg = *reinterpret_cast<const h8_t*>(p.bias + Nh + n0 + ch * 8);
+                h8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float hid = sp[j] + (float)bh[j];
+                    const float gate = sp[32 + j] + (float)bg[j];
+                    // diffusers: proj output is an fp16 tensor; hidden * gelu(gate) with gelu's result in fp16
+                    o[j] = (half_t)((float)(half_t)hid * (float)(half_t)gelu_erf((float)(half_t)gate));
+                }
+                *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
+            }
+        }
+    } else {
+        // output tile 128 x 64: 8 chunks per row -> 1024 chunks, 4 per thread; a row's 8 chunks = one 128-B segment
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
+            if (m0 + row < p.M) {
+                const float* sp = stage + row * kEpiStride + ch * 8;
+                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
+                if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
+                h8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)(sp[j] + (float)bv[j] + (float)rv[j]);
+                *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
+            }
+        }
+    }
+}
+
+bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                              int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu, int dtype,
+                              void* stream) {
+    if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
+    if (K % BK != 0 || N % BN != 0 || ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;
+    if (geglu && (!bias || residual || (N / 2) % 32 != 0)) return DSC_ERR_UNSUPPORTED;
+    if (!al16(x) || !al16(w) || !al16(out) || (bias && !al16(bias)) || (residual && !al16(residual))) return DSC_ERR_UNSUPPORTED;
+    if (M > (1ll << 30)) return DSC_ERR_UNSUPPORTED;
+    GemmParams p{};
+    p.x = static_cast<const half_t*>(x); p.w = static_cast<const half_t*>(w);
+    p.bias = static_cast<const half_t*>(bias); p.res = static_cast<const half_t*>(residual);
+    p.out = static_cast<half_t*>(out);
+    p.M = (int)M; p.N = N; p.K = K; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
+    const int mb = (int)((M + BM - 1) / BM);
+    const int nb = geglu ? N / 64 : N / BN;
+    constexpr int kStages = 3;                                        // 72 KiB -> 2 workgroups per CU, 4 K tiles in flight
+    const size_t lds = (size_t)kStages * kStage * sizeof(half_t);    // the fp32 epilogue stage (34 KiB) reuses it
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, kStages>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, kStages>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (geglu) hipLaunchKernelGGL((gemm_tn_f16<true, kStages>), dim3(mb * nb), dim3(T), lds, st, p);
+    else hipLaunchKernelGGL((gemm_tn_f16<false, kStages>), dim3(mb * nb), dim3(T), lds, st, p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}

@@ -200,13 +200,14 @@ class _RegionProcessor:
         if is_self and fused_qkv is not None and attn.to_q.bias is None:
             # self-attention: q, k, v from ONE [3C, C] GEMM; the three [B, L, H, d] operands are strided views of it
             B, L, _ = hidden_states.shape
-            qkv = F.linear(hidden_states, fused_qkv())
+            qkv = ops.linear(hidden_states, fused_qkv())
             C = qkv.shape[-1] // 3
             d = C // H
             S = L
             q4, k4, v4 = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
         else:
-            query = attn.to_q(hidden_states)
+            query = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias) if type(attn.to_q) is nn.Linear \
+                else attn.to_q(hidden_states)
             if is_self:
                 encoder_hidden_states = hidden_states
             elif attn.norm_cross:
@@ -238,7 +239,9 @@ class _RegionProcessor:
         else:
             out = ops.self_attention(q4, k4, v4, scale=sc)                  # [B, L, H, d]
         hidden_states = out.reshape(B, L, C)
-        hidden_states = attn.to_out[0](hidden_states)
+        to_out = attn.to_out[0]
+        hidden_states = ops.linear(hidden_states, to_out.weight, to_out.bias) if type(to_out) is nn.Linear \
+            else to_out(hidden_states)
         hidden_states = attn.to_out[1](hidden_states)
         if input_ndim == 4:
             hidden_states = hidden_states.transpose(-1, -2).reshape(batch_size, channel, height, width)

@@ -109,14 +109,12 @@ class Conv1x1(nn.Conv2d):
     def __init__(self, cin, cout):
         super().__init__(cin, cout, 1)
 
-    def tokens(self, t, bias=None):
-        return F.linear(t, self.weight.flatten(1), self.bias if bias is None else bias)
+    def tokens(self, t, bias=None, residual=None):
+        return ops.linear(t, self.weight.flatten(1), self.bias if bias is None else bias, residual=residual)
 
     def forward(self, x, residual=None):
         b, c, h, w = x.shape
-        y = self.tokens(_tokens(x))
-        if residual is not None:
-            y = y + _tokens(residual)
+        y = self.tokens(_tokens(x), residual=None if residual is None else _tokens(residual))
         return _image(y, h, w)
 
 
@@ -203,7 +201,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        return ops.geglu(self.proj(x))
+        return ops.linear(x, self.proj.weight, self.proj.bias, geglu=True)     # GEMM + bias + GEGLU in one kernel
 
 
 class FeedForward(nn.Module):
@@ -211,10 +209,9 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
 
-    def forward(self, x):
-        for m in self.net:
-            x = m(x)
-        return x
+    def forward(self, x, residual=None):
+        h = self.net[0](x)
+        return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)   # net[1] is Dropout(0)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -231,7 +228,7 @@ class BasicTransformerBlock(nn.Module):
         kw = cross_attention_kwargs or {}
         x = self.attn1(self.norm1(x), None, **kw) + x          # the same kwargs reach self- and cross-attention
         x = self.attn2(self.norm2(x), encoder_hidden_states, **kw) + x
-        return self.ff(self.norm3(x)) + x
+        return self.ff(self.norm3(x), residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -254,8 +251,11 @@ class Transformer2DModel(nn.Module):
         t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
         for blk in self.transformer_blocks:
             t = blk(t, encoder_hidden_states, cross_attention_kwargs)
-        t = self.proj_out(t) if self.use_linear_projection else self.proj_out.tokens(t)
-        return _image(t + _tokens(x), h, w)
+        if self.use_linear_projection:
+            t = ops.linear(t, self.proj_out.weight, self.proj_out.bias, residual=_tokens(x))
+        else:
+            t = self.proj_out.tokens(t, residual=_tokens(x))
+        return _image(t, h, w)
 
 
 class ResnetBlock2D(nn.Module):
@@ -285,7 +285,7 @@ class ResnetBlock2D(nn.Module):
         b = _derived(self, "sb", (self.conv_shortcut.bias, self.conv2.bias),
                      lambda: (self.conv_shortcut.bias + self.conv2.bias).contiguous())
         bsz, _, hh, ww = h.shape
-        return _image(self.conv_shortcut.tokens(_tokens(x), bias=b) + _tokens(h), hh, ww)
+        return _image(self.conv_shortcut.tokens(_tokens(x), bias=b, residual=_tokens(h)), hh, ww)
 
 
 class Downsample2D(nn.Module):

@@ -270,6 +270,47 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
     return y
 
 
+USE_DSC_GEMM = True        # route qualifying linears to dsc_linear_f16 (False: always hipBLASLt through torch)
+DSC_GEMM_MIN_ROWS = 1024   # measured (tools/mb_gemm.py): the 128x64x64-tile kernel beats hipBLASLt + separate epilogue
+DSC_GEMM_MAX_K = 640       # kernels for >= 1024 token rows and K <= 640; hipBLASLt's larger macro-tiles win beyond
+
+
+def linear(x, weight, bias=None, residual=None, geglu=False):
+    """x @ weight.T (+ bias) (+ residual), or the fused GEGLU of [x @ weight.T + bias]; x [..., K], weight [N, K].
+
+    Shapes the hand-written MFMA kernel covers (fp16, K % 64 == 0, N % 64 == 0, >= DSC_GEMM_MIN_ROWS rows, unit inner
+    stride) go to dsc_linear_f16 with the epilogue fused; everything else is a plain library GEMM through torch
+    (hipBLASLt) followed by the separate epilogue ops."""
+    _require_gpu(x, weight)
+    N, K = weight.shape
+    lead = x.shape[:-1]
+    M = 1
+    for v in lead:
+        M *= v
+    ok = (USE_DSC_GEMM and x.dtype == torch.float16 and weight.dtype == torch.float16 and K % 64 == 0 and N % 64 == 0
+          and M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K and x.stride(-1) == 1 and weight.is_contiguous()
+          and (not geglu or (bias is not None and residual is None and (N // 2) % 32 == 0)))
+    x2 = None
+    if ok:
+        x2 = x.reshape(M, K)                      # a view when the leading dims collapse (the token-major case)
+        ok = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
+    if ok and residual is not None:
+        r2 = residual.reshape(M, N)
+        ok = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
+    if not ok:
+        y = torch.nn.functional.linear(x, weight, bias)
+        if geglu:
+            return globals()["geglu"](y)
+        return y if residual is None else y + residual
+    n_out = N // 2 if geglu else N
+    out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    rc = _lib.load_library().dsc_linear_f16(_p(x2), _p(weight), _p(bias), _p(r2) if residual is not None else None, _p(out),
+                                            M, N, K, x2.stride(0), r2.stride(0) if residual is not None else 0, n_out,
+                                            1 if geglu else 0, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_linear_f16")
+    return out.reshape(*lead, n_out)
+
+
 def add_bias_residual(a, b, bias=None):
     """a + b + bias[c] over channels-last / token-major fp16 tensors of identical layout (dsc_add_bias_residual)."""
     _require_gpu(a, b)

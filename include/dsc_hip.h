@@ -197,6 +197,18 @@ int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const voi
 int dsc_add_bias_residual(const void* a, const void* b, const void* bias, void* out, int64_t rows, int C,
                           int dtype, void* stream);
 
+/*
+ * Token-major fp16 linear with fused epilogues - replaces `F.linear` (+ the separate residual add / GEGLU kernels) for
+ * the UNet's `to_q/to_k/to_v/to_out`, feed-forward and 1x1 projection layers (diffusers BasicTransformerBlock /
+ * Transformer2DModel / ResnetBlock2D shortcut):
+ *   geglu == 0:  out[m, n] = sum_k x[m,k] w[n,k] (+ bias[n]) (+ residual[m,n]),            out is [M, N]
+ *   geglu == 1:  out[m, j] = (acc[m,j] + bias[j]) * gelu(acc[m,N/2+j] + bias[N/2+j]),      out is [M, N/2]
+ * x [M, K] with row stride ldx, w [N, K] contiguous (torch Linear layout), residual / out with row strides ldr / ldo.
+ * Requirements: fp16, K % 64 == 0, N % 64 == 0, strides % 8 == 0, 16-byte aligned pointers; geglu needs bias, no residual.
+ */
+int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                   int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu, int dtype, void* stream);
+
 /* GEGLU of the transformer feed-forward (diffusers GEGLU): y[r, j] = x[r, j] * gelu(x[r, n + j]), exact erf gelu.
  * x fp16 [rows, 2n] contiguous, y fp16 [rows, n]; n % 8 == 0. */
 int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);

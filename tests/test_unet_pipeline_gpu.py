@@ -91,6 +91,49 @@ def test_self_attention(ops, B, H, L, d):
         assert (out2.float().cpu() - ref2).abs().max().item() < 3e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 320, 320), (8192, 960, 320), (8192, 320, 1280), (2048, 640, 640), (2048, 640, 2560),
+                                   (512, 1280, 1280), (512, 3840, 1280), (300, 64, 64), (8192, 320, 960), (256, 1280, 5120)])
+def test_linear_kernel(ops, M, N, K):
+    """dsc_linear_f16 vs fp32 matmul on fp16-representable operands: one fp16 rounding of the fp32 result."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half()
+    b = (torch.randn(N, generator=g) * 0.2).half()
+    r = torch.randn(M, N, generator=g).half()
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    xd, wd, bd, rd = x.cuda(), w.cuda(), b.cuda(), r.cuda()
+    out = ops.linear(xd, wd, bd, residual=rd)
+    assert out.shape == (M, N)
+    assert torch.all((out.float().cpu() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3)
+    out2 = ops.linear(xd, wd, None)
+    ref2 = x.float() @ w.float().t()
+    assert torch.all((out2.float().cpu() - ref2).abs() <= 1.5e-3 * ref2.abs() + 2e-3)
+    assert torch.equal(out, ops.linear(xd, wd, bd, residual=rd))
+    # strided activation rows (a [B, L, 3C] slice) and 3-D input
+    big = torch.randn(2, M // 2, K + 64, generator=g).half().cuda()
+    xv = big[..., :K]
+    o3 = ops.linear(xv, wd, bd)
+    ref3 = xv.float().cpu() @ w.float().t() + b.float()
+    assert o3.shape == (2, M // 2, N)
+    assert torch.all((o3.float().cpu() - ref3).abs() <= 1.5e-3 * ref3.abs() + 2e-3)
+
+
+@pytest.mark.parametrize("M,C", [(8192, 320), (2048, 640), (512, 1280), (300, 64)])
+def test_linear_geglu_kernel(ops, M, C):
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).half()
+    w = (torch.randn(8 * C, C, generator=g) / math.sqrt(C)).half()
+    b = (torch.randn(8 * C, generator=g) * 0.2).half()
+    y = (x.float() @ w.float().t() + b.float()).half().float()            # the projection output is an fp16 tensor
+    hid, gate = y.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate).half().float()
+    out = ops.linear(x.cuda(), w.cuda(), b.cuda(), geglu=True)
+    assert out.shape == (M, 4 * C)
+    err = (out.float().cpu() - ref).abs()
+    assert torch.all(err <= 4e-3 * ref.abs() + 4e-3), err.max().item()    # a flipped fp16 rounding of hid or gate moves the product by 1 ulp of each
+    assert err.mean().item() < 3e-4
+
+
 def test_geglu(ops):
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(2, 100, 2 * 1280, generator=g) * 2).half()

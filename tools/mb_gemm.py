@@ -1,0 +1,32 @@
+"""microbench: dsc_linear_f16 vs hipBLASLt (graph-captured launches)"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from diffusionspatialcontrol_amd import ops
+dev = "cuda"
+def tm_graph(fn, n=30, reps=5):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(3): fn()
+    st.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
+    g.replay(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): g.replay()
+    e.record(); e.synchronize()
+    return s.elapsed_time(e) / (n * reps) * 1e3
+for (M, N, K, geglu) in [(8192, 320, 320, 0), (8192, 960, 320, 0), (8192, 2560, 320, 1), (8192, 320, 1280, 0), (2048, 640, 640, 0), (2048, 1920, 640, 0),
+                         (2048, 5120, 640, 1), (2048, 640, 2560, 0), (512, 1280, 1280, 0), (512, 3840, 1280, 0), (512, 10240, 1280, 1), (512, 1280, 5120, 0),
+                         (128, 1280, 1280, 0), (128, 10240, 1280, 1), (128, 1280, 5120, 0)]:
+    x = torch.randn(M, K, device=dev).half(); w = torch.randn(N, K, device=dev).half(); b = torch.randn(N, device=dev).half()
+    r = torch.randn(M, N, device=dev).half()
+    ops.DSC_GEMM_MIN_ROWS = 1
+    if geglu:
+        t1 = tm_graph(lambda: ops.linear(x, w, b, geglu=True)); t2 = tm_graph(lambda: ops.geglu(F.linear(x, w, b)))
+    else:
+        t1 = tm_graph(lambda: ops.linear(x, w, b, residual=r)); t2 = tm_graph(lambda: F.linear(x, w, b) + r)
+    fl = 2.0 * M * N * K
+    print(f"M{M} N{N} K{K} {'geglu' if geglu else 'bias+res'}: ours {t1:7.2f} us ({fl/t1/1e6:5.0f} TF)   hipBLASLt+epilogue kernels {t2:7.2f} us ({fl/t2/1e6:5.0f} TF)", flush=True)
