@@ -59,6 +59,7 @@ _SIGNATURES = {
     "dsc_add_bias_residual": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_linear_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                        [ctypes.c_int, ctypes.c_int, _vp]),
+    "dsc_add_layernorm": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_geglu": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
 }
 

@@ -226,9 +226,13 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, encoder_hidden_states, cross_attention_kwargs):
         kw = cross_attention_kwargs or {}
-        x = self.attn1(self.norm1(x), None, **kw) + x          # the same kwargs reach self- and cross-attention
-        x = self.attn2(self.norm2(x), encoder_hidden_states, **kw) + x
-        return self.ff(self.norm3(x), residual=x)
+        # `x = attn(norm(x)) + x; h = next_norm(x)` pairs run as ONE add+LayerNorm launch (the same kwargs reach self-
+        # and cross-attention, as in diffusers' BasicTransformerBlock)
+        _, h = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x, h = ops.add_layernorm(x, self.attn1(h, None, **kw), self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        x, h = ops.add_layernorm(x, self.attn2(h, encoder_hidden_states, **kw), self.norm3.weight, self.norm3.bias,
+                                 self.norm3.eps)
+        return self.ff(h, residual=x)
 
 
 class Transformer2DModel(nn.Module):

@@ -331,6 +331,24 @@ def add_bias_residual(a, b, bias=None):
     return out
 
 
+def add_layernorm(x, a, weight, bias, eps=1e-5):
+    """(x + a, LayerNorm(x + a)) in one launch (dsc_add_layernorm); a may be None -> (x, LayerNorm(x)).
+    x, a: [..., C] fp16 contiguous."""
+    _require_gpu(x)
+    x = x.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    s = x
+    if a is not None:
+        a = a.contiguous()
+        s = torch.empty_like(x)
+    rc = _lib.load_library().dsc_add_layernorm(_p(x), _p(a), _p(weight), _p(bias), _p(s) if a is not None else None, _p(y),
+                                               rows, C, float(eps), 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_add_layernorm")
+    return s, y
+
+
 def geglu(x):
     """hidden * gelu(gate) for x = [..., 2n] fp16 contiguous (dsc_geglu)."""
     _require_gpu(x)

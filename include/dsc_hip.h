@@ -209,6 +209,16 @@ int dsc_add_bias_residual(const void* a, const void* b, const void* bias, void* 
 int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                    int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu, int dtype, void* stream);
 
+/*
+ * (residual add +) LayerNorm over the last dimension - replaces the `x = attn(...) + x` elementwise add and the
+ * `nn.LayerNorm` that follows it in diffusers' BasicTransformerBlock (norm1/norm2/norm3, eps 1e-5):
+ *   s[r, :]  = x[r, :] + a[r, :]            (a == NULL: s = x)         -> written to `sum_out` when non-NULL (fp16)
+ *   y[r, :]  = (s - mean_r) * rstd_r * gamma + beta                     statistics in fp32 on the fp16-rounded s
+ * rows x C fp16, contiguous rows; C % 8 == 0, C <= 4096.  One wave per row, 16-byte accesses, one launch.
+ */
+int dsc_add_layernorm(const void* x, const void* a, const void* gamma, const void* beta, void* sum_out, void* y,
+                      int64_t rows, int C, float eps, int dtype, void* stream);
+
 /* GEGLU of the transformer feed-forward (diffusers GEGLU): y[r, j] = x[r, j] * gelu(x[r, n + j]), exact erf gelu.
  * x fp16 [rows, 2n] contiguous, y fp16 [rows, n]; n % 8 == 0. */
 int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);

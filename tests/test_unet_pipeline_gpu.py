@@ -134,6 +134,22 @@ def test_linear_geglu_kernel(ops, M, C):
     assert err.mean().item() < 3e-4
 
 
+@pytest.mark.parametrize("rows,C", [(8192, 320), (2048, 640), (512, 1280), (77, 64), (5, 4096), (1000, 2560)])
+def test_add_layernorm(ops, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).half()
+    a = torch.randn(rows, C, generator=g).half()
+    gamma, beta = (torch.randn(C, generator=g) * 0.3 + 1).half(), (torch.randn(C, generator=g) * 0.2).half()
+    s_ref = (x.float() + a.float()).half()
+    y_ref = F.layer_norm(s_ref.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    s, y = ops.add_layernorm(x.cuda(), a.cuda(), gamma.cuda(), beta.cuda())
+    assert torch.equal(s.cpu(), s_ref)
+    assert torch.all((y.float().cpu() - y_ref).abs() <= 1.5e-3 * y_ref.abs() + 2e-3)
+    s0, y0 = ops.add_layernorm(x.cuda(), None, gamma.cuda(), beta.cuda())
+    y0_ref = F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    assert torch.all((y0.float().cpu() - y0_ref).abs() <= 1.5e-3 * y0_ref.abs() + 2e-3)
+
+
 def test_geglu(ops):
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(2, 100, 2 * 1280, generator=g) * 2).half()
