@@ -4,10 +4,13 @@
 // EVERY row: the statistics are column sums.  A workgroup owns a chunk of rows of one image and ALL groups:
 // thread t reads the fixed 16-byte channel vector c8 = t % (C/8) of rows slice, slice+k, ... (k = row slices per
 // workgroup), so every load/store is a coalesced 16-byte access and the per-channel constants stay in registers.
-//   launch 1 gn_nhwc_stats : per-thread channel sums -> LDS [k][C] -> per-channel -> per-group (sum, sumsq) in
-//                            fp64 -> partials[b][chunk][g]
-//   launch 2 gn_nhwc_apply : re-adds the chunk partials (fixed order), folds mean/rstd/gamma/beta(/add) into one
-//                            scale+shift per channel, streams its rows: y = silu(x*sc + sh)
+//   launch 1 gn_nhwc_stats    : per-thread channel sums -> LDS [k][C] -> per-channel -> per-group (sum, sumsq) in
+//                               fp64 -> partials[b][chunk][g]
+//   launch 2 gn_nhwc_finalize : one workgroup per image adds the chunk partials (fixed order) -> (mean, rstd)[b][g].
+//                               Without it every apply workgroup re-read all nchunk x G partials (64 KB, more than
+//                               its own 40 KB of activations)
+//   launch 3 gn_nhwc_apply    : folds mean/rstd/gamma/beta(/add) into one scale+shift per channel, streams its rows:
+//                               y = silu(x*sc + sh)
 // HBM-bound: algorithmic bytes = 2 * B*hw*C*2 (read + write); the second read hits L2 / Infinity Cache.
 #include "dsc_common.h"
 #include "dsc_hip.h"
@@ -19,6 +22,7 @@ constexpr int kMaxT = 512;
 struct GnN {
     const half_t* x; half_t* y; const half_t* gamma; const half_t* beta; const half_t* add;
     double* partials;            // [B][nchunk][G][2]
+    float* stats;                // [B][G][2] (mean, rstd), behind the partials in the workspace
     int B, HW, C, G, cpg, cv, k, nchunk, rows;
     long long add_stride;
     float eps; int silu;
@@ -59,30 +63,36 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
     }
 }
 
+__global__ __launch_bounds__(256) void gn_nhwc_finalize(GnN p) {
+    __shared__ double red[256 * 2];
+    const int b = blockIdx.x;
+    const int np = 256 / p.G;                                // G <= 64
+    const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+    double a1 = 0.0, a2 = 0.0;
+    if (part < np) {
+        const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
+        for (int i = part; i < p.nchunk; i += np) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+    }
+    red[2 * threadIdx.x] = a1; red[2 * threadIdx.x + 1] = a2;
+    __syncthreads();
+    if (threadIdx.x < p.G) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < np; ++q) { t1 += red[2 * (q * p.G + g)]; t2 += red[2 * (q * p.G + g) + 1]; }
+        const double n = (double)p.HW * p.cpg;
+        const double m = t1 / n;
+        double var = t2 / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        p.stats[((long long)b * p.G + g) * 2] = (float)m;
+        p.stats[((long long)b * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+}
+
 __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     __shared__ float mean_s[64], rstd_s[64];
-    __shared__ double red[kMaxT * 2];
     const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
-    {   // all threads re-add the chunk partials: thread (g, part) takes chunks part, part+np, ...; fixed order
-        const int T = blockDim.x, np = T / p.G;              // T >= G always (cv*k >= 32 for C >= 256; checked in plan)
-        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
-        double a1 = 0.0, a2 = 0.0;
-        if (part < np) {
-            const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
-            for (int i = part; i < p.nchunk; i += np) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
-        }
-        red[2 * threadIdx.x] = a1; red[2 * threadIdx.x + 1] = a2;
-        __syncthreads();
-        if (threadIdx.x < p.G) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int q = 0; q < np; ++q) { t1 += red[2 * (q * p.G + g)]; t2 += red[2 * (q * p.G + g) + 1]; }
-            const double n = (double)p.HW * p.cpg;
-            const double m = t1 / n;
-            double var = t2 / n - m * m;
-            var = var > 0.0 ? var : 0.0;
-            mean_s[g] = (float)m;
-            rstd_s[g] = (float)(1.0 / sqrt(var + (double)p.eps));
-        }
+    if (threadIdx.x < p.G) {
+        mean_s[threadIdx.x] = p.stats[((long long)b * p.G + threadIdx.x) * 2];
+        rstd_s[threadIdx.x] = p.stats[((long long)b * p.G + threadIdx.x) * 2 + 1];
     }
     __syncthreads();
     const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
@@ -121,9 +131,8 @@ bool plan(GnN& p) {
     p.k = 256 / p.cv;
     if (p.k < 1) p.k = 1;
     while (p.cv * p.k < p.G) ++p.k;                          // the partial re-add needs >= G threads
-    int target = 768 / p.B;                                  // ~3 workgroups per CU
+    int target = 512 / p.B;                                  // ~2 workgroups per CU
     if (target < 1) target = 1;
-    if (target > 128) target = 128;                          // bounds the per-workgroup partial re-add
     int min_rows = 2 * p.k;                                  // at least two rows per thread
     int nchunk = (p.HW + min_rows - 1) / min_rows;
     if (nchunk > target) nchunk = target;
@@ -168,7 +177,7 @@ extern "C" size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int g
     GnN p{};
     p.B = B; p.C = C; p.HW = hw; p.G = groups;
     if (B <= 0 || C <= 0 || hw <= 0 || groups <= 0 || !plan(p)) return 0;
-    return (size_t)B * p.nchunk * groups * 2 * sizeof(double);
+    return (size_t)B * p.nchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
 }
 
 extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, const void* add,
@@ -181,17 +190,19 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     if (!plan(p)) return DSC_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta) || (add && (!al16(add) || add_row_stride % 8 != 0 || add_row_stride < C)))
         return DSC_ERR_UNSUPPORTED;
-    const size_t need = (size_t)B * p.nchunk * groups * 2 * sizeof(double);
+    const size_t need = (size_t)B * p.nchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;
     p.x = static_cast<const half_t*>(x); p.y = static_cast<half_t*>(y);
     p.gamma = static_cast<const half_t*>(gamma); p.beta = static_cast<const half_t*>(beta);
     p.add = static_cast<const half_t*>(add);
     p.add_stride = add_row_stride;
     p.partials = static_cast<double*>(workspace);
+    p.stats = reinterpret_cast<float*>(p.partials + (size_t)B * p.nchunk * groups * 2);
     p.eps = eps; p.silu = apply_silu;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(B * p.nchunk), block(p.cv * p.k);
     hipLaunchKernelGGL(gn_nhwc_stats, grid, block, (size_t)2 * p.k * C * sizeof(float), st, p);
+    hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B), dim3(256), 0, st, p);
     hipLaunchKernelGGL(gn_nhwc_apply, grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
