@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--regions", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-miopen-find", action="store_true",
+                    help="skip MIOpen's exhaustive solver search (cudnn.benchmark + MIOPEN_FIND_MODE=1) during warm-up")
     ap.add_argument("--deterministic-conv", action="store_true",
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
                          "falls back to kernels >10x slower on this image; off by default")
@@ -136,7 +138,7 @@ def roofline_region_xattn(dev, n_img):
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pj):
         try:
-            traffic = json.load(open(pj)).get("xp_fwd_hbm_bytes_per_launch")
+            traffic = json.load(open(pj)).get("xp_fwd_hbm_bytes_per_launch") if n_img == 1 else None   # measured at Bc=2
         except Exception:  # noqa: BLE001
             traffic = None
     return {"kernel": "xp_fwd<3,false> (region cross-attention forward, L=4096 C=320 S=77, Bc=%d)" % Bc,
@@ -202,6 +204,9 @@ def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sampl
 
 def main():
     a = parse()
+    if not a.no_miopen_find:
+        os.environ.setdefault("MIOPEN_FIND_MODE", "1")         # must be set before MIOpen initialises
+        torch.backends.cudnn.benchmark = True                   # let MIOpen time its solvers per conv shape (warm-up only)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -62,7 +62,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 
 // GEGLU: the workgroup's 64 weight rows are 32 "hidden" rows n0h.. and the 32 matching "gate" rows N/2 + n0h..
 template <bool GEGLU, int STAGES>
-__global__ __launch_bounds__(T, 2) void gemm_tn_f16(GemmParams p) {
+__global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* lds = reinterpret_cast<half_t*>(smem);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -108,7 +108,9 @@ __global__ __launch_bounds__(T, 2) void gemm_tn_f16(GemmParams p) {
         const int buf = kt % STAGES;
         // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (6 DMA instructions each) are outstanding
         const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (younger >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // raw: publishes tile kt, proves tile kt-1's reads are done
@@ -195,18 +197,20 @@ extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, co
     p.M = (int)M; p.N = N; p.K = K; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     const int mb = (int)((M + BM - 1) / BM);
     const int nb = geglu ? N / 64 : N / BN;
-    constexpr int kStages = 3;                                        // 72 KiB -> 2 workgroups per CU, 4 K tiles in flight
-    const size_t lds = (size_t)kStages * kStage * sizeof(half_t);    // the fp32 epilogue stage (34 KiB) reuses it
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, kStages>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, kStages>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (geglu) hipLaunchKernelGGL((gemm_tn_f16<true, kStages>), dim3(mb * nb), dim3(T), lds, st, p);
-    else hipLaunchKernelGGL((gemm_tn_f16<false, kStages>), dim3(mb * nb), dim3(T), lds, st, p);
+    // 3 stages = 72 KiB -> two workgroups per CU.  A deeper ring (6 stages) was measured and changes nothing: a K tile
+    // costs ~1000 cycles because a CU ingests only ~24 B/cycle from L2 (24 KiB per tile), not because of DMA latency -
+    // the kernel is L2->LDS bandwidth bound at this tile size (43 FLOP per staged byte), which caps it near 25 % of the
+    // MFMA peak; the dispatch in ops.linear therefore sends long-K shapes to hipBLASLt's larger macro-tiles.
+    const size_t lds = (size_t)3 * kStage * sizeof(half_t);          // the fp32 epilogue stage (34 KiB) reuses it
+    const dim3 grid(mb * nb), block(T);
+    if (geglu) hipLaunchKernelGGL((gemm_tn_f16<true, 3>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
