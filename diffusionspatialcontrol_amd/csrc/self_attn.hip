@@ -295,6 +295,10 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         (void)wg4x2;    // measured: two query tiles per wave lose to one (220+ VGPRs -> 1 wave/SIMD): tuning variant only
         if (g_sa_variant == 2) return launch<NK, 4, (NK <= 4 ? 2 : 1)>(p, st);
     }
+    // 8 waves (256 query rows share each K/V tile: half the L2->LDS traffic per MFMA) once that still leaves >= 2
+    // workgroups per CU: +11 % at Bc = 16, nothing at Bc = 2 (tools/mb_sa.py)
+    const long long wg8 = (long long)p.Bc * p.H * ((p.L + 255) / 256);
+    if (NK <= 5 && ((g_sa_variant == 0 && wg8 >= 512) || g_sa_variant == 3)) return launch<(NK <= 5 ? NK : 3), 8, 1>(p, st);
     if (wg4 >= 256 || g_sa_variant == 1) return launch<NK, 4, 1>(p, st);
     const long long wg2 = (long long)p.Bc * p.H * ((p.L + 63) / 64);
     if (wg2 >= 128 || NK >= 6) return launch<NK, 2, 1>(p, st);   // one wave alone would need 160 staging registers at d = 160
