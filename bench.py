@@ -213,12 +213,17 @@ def main():
     dist = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    local = local % torch.cuda.device_count()                 # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist:
         import torch.distributed as td
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", device_id=dev)          # "nccl" is RCCL on ROCm
+        backend = os.environ.get("DSC_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(backend)
 
     from diffusionspatialcontrol_amd import ops
     from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline

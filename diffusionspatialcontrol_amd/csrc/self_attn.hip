@@ -33,6 +33,7 @@ struct SaParams {
     int nqb, xcd_map;
     float scale_log2e;
     long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
+    unsigned long long* stamps;
 };
 
 template <int NK>
@@ -42,6 +43,13 @@ struct SaCfg {
     static constexpr int VP = (DM <= 3) ? 96 : 160;         // V row stride: (VP/2) % 64 in {16, 48} -> tr reads conflict-free
     static constexpr int TILE_HALVES = kKV * KP + kKV * VP; // one (K, V) buffer
 };
+
+// Prefetch load that hipcc's s_waitcnt insertion does not see (cdna_hip_programming.md section 5.7 form (ii)): the compiler
+// otherwise waits vmcnt(0) before the FIRST MFMA after the loads - exposing the full memory latency every tile - because
+// it reuses the loads' address registers.  The matching wait is stage_wait() right before the LDS write.
+__device__ __forceinline__ void hidden_load(h8_t& dst, const half_t* src) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
 
 __device__ __forceinline__ h4_t tr_read(const half_t* p) {
     const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -53,6 +61,17 @@ __device__ __forceinline__ h4_t tr_read(const half_t* p) {
 // ONES (NK odd: the PV row tile has >= 16 padding channels): V's first padding column holds 1.0, so the PV MFMA
 // returns sum_s p[s] in output channel 16*NK for free - no per-score adds, and the sum uses the same fp16-rounded p as
 // the numerator.
+unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cycle sums of workgroup 0 / wave 0
+
+#define SA_STAMP(slot)                                                                          \
+    if (dbg) {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                             \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                     \
+        seg[slot] += t_ - tprev; tprev = t_;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+
 template <int NK, int WAVES, int QT>
 __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
     using C = SaCfg<NK>;
@@ -105,15 +124,32 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
     }
 
     h8_t kst[CH], vst[CH];                                   // staging registers for the next tile
+    // per-thread staging geometry, fixed for the whole kernel: chunk c of this thread is row srow[c], 16-byte column scol[c]
+    int srow[CH], scol[CH];
+    const half_t* kptr[CH];
+    const half_t* vptr[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int idx = threadIdx.x + c * T;
+        srow[c] = idx / d8;
+        scol[c] = idx - srow[c] * d8;
+        kptr[c] = kg + (long long)srow[c] * p.kss + scol[c] * 8;
+        vptr[c] = vg + (long long)srow[c] * p.vss + scol[c] * 8;
+    }
+    const long long ktile = (long long)kKV * p.kss, vtile = (long long)kKV * p.vss;
     auto stage_load = [&](int tile) {
+        const bool ragged = (tile + 1) * kKV > p.S;              // wave-uniform: only the last tile can run past S
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int idx = threadIdx.x + c * T;
-            const int row = idx / d8, col = idx - row * d8;
-            if (idx < kKV * d8) {
-                const int kv = min(tile * kKV + row, p.S - 1);
-                kst[c] = *reinterpret_cast<const h8_t*>(kg + (long long)kv * p.kss + col * 8);
-                vst[c] = *reinterpret_cast<const h8_t*>(vg + (long long)kv * p.vss + col * 8);
+            if (srow[c] < kKV) {
+                long long ko = (long long)tile * ktile, vo = (long long)tile * vtile;
+                if (ragged) {                                    // clamp the row to the last valid key (masked in the softmax)
+                    const int back = max(tile * kKV + srow[c] - (p.S - 1), 0);
+                    ko -= (long long)back * p.kss;
+                    vo -= (long long)back * p.vss;
+                }
+                hidden_load(kst[c], kptr[c] + ko);
+                hidden_load(vst[c], vptr[c] + vo);
             }
         }
     };
@@ -121,12 +157,13 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         half_t* Kb = lds + buf * C::TILE_HALVES;
         half_t* Vb = Kb + kKV * KP;
 #pragma unroll
+        for (int c = 0; c < CH; ++c)                             // the hidden loads have landed: name every destination
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kst[c]), "+v"(vst[c]) :: "memory");
+#pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int idx = threadIdx.x + c * T;
-            const int row = idx / d8, col = idx - row * d8;
-            if (idx < kKV * d8) {
-                *reinterpret_cast<h8_t*>(Kb + row * KP + col * 8) = kst[c];
-                *reinterpret_cast<h8_t*>(Vb + row * VP + col * 8) = vst[c];
+            if (srow[c] < kKV) {
+                *reinterpret_cast<h8_t*>(Kb + srow[c] * KP + scol[c] * 8) = kst[c];
+                *reinterpret_cast<h8_t*>(Vb + srow[c] * VP + scol[c] * 8) = vst[c];
             }
         }
     };
@@ -151,10 +188,14 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
     // per-lane constant part of the transposed-read address: row (4 hh + (i >> 2)), column 16 * ((lane >> 4) & 1) + 4 * (i & 3)
     const int tr_off = (4 * hh + ((lane & 15) >> 2)) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     const float c2 = p.scale_log2e;
+    const bool dbg = p.stamps != nullptr && blockIdx.x == 0 && wave == 0;
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) stage_load(t + 1);               // in flight during this tile's MFMAs
+        SA_STAMP(0)
         const half_t* Kb = lds + buf * C::TILE_HALVES;
         const half_t* Vb = Kb + kKV * KP;
 
@@ -175,6 +216,8 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
                 for (int qt = 0; qt < QT; ++qt) s[qt][m] = mfma_32x32x16(kf, qf[qt][ks], s[qt][m]);
             }
 
+        if (dbg) asm volatile("" :: "v"(s[0][0][0]), "v"(s[0][1][15]));
+        SA_STAMP(1)
         // ---- online softmax, base 2, lazy rescale.  Element i of s[qt][m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh.
         const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
         h8_t pf[QT][4];
@@ -220,6 +263,7 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
             if (!ONES) l_run[qt] += psum;
         }
 
+        SA_STAMP(2)
         // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels); V^T fragments shared by the QT tiles
 #pragma unroll
         for (int dm = 0; dm < DM; ++dm) {
@@ -233,9 +277,15 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
                 for (int qt = 0; qt < QT; ++qt) o[qt][dm] = mfma_32x32x16(vf, pf[qt][tt], o[qt][dm]);
             }
         }
+        if (dbg) asm volatile("" :: "v"(o[0][0][0]), "v"(o[0][DM - 1][15]));
+        SA_STAMP(3)
         if (t + 1 < ntiles) stage_write(buf ^ 1);            // buffer buf^1 was last read in iteration t-1
+        SA_STAMP(4)
         __syncthreads();
+        SA_STAMP(5)
     }
+    if (dbg && lane == 0)
+        for (int i = 0; i < 6; ++i) p.stamps[i] = seg[i];
 
     // ---- epilogue: O / l, fp16, out[b, q, h, :]
 #pragma unroll
@@ -311,6 +361,7 @@ bool strides_ok(const int64_t s[3]) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s
 }  // namespace
 
 extern "C" void dsc_debug_set_self_attn_variant(int v) { g_sa_variant = v; }
+extern "C" void dsc_debug_set_self_attn_stamps(void* device_buffer_64B) { g_sa_stamps = static_cast<unsigned long long*>(device_buffer_64B); }
 
 extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, void* out, int Bc, int H, int L, int S,
                                  int d, const int64_t q_strides[3], const int64_t k_strides[3],
@@ -331,6 +382,7 @@ extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, vo
     p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
     p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
     p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
+    p.stamps = g_sa_stamps;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d <= 48) return launch_nk<3>(p, st);
     if (d <= 64) return launch_nk<4>(p, st);

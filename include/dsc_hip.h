@@ -51,6 +51,8 @@ void dsc_debug_set_stamp_buffer(void* device_buffer_2KiB);
 /* Tuning aid: force a tiling variant of the flash self-attention kernel (0 = automatic choice, 1 = one query tile per
  * wave, 2 = two query tiles per wave where the head dim allows it). */
 void dsc_debug_set_self_attn_variant(int variant);
+/* Diagnostic: 6 x u64 per-segment cycle sums of workgroup 0 / wave 0 of the flash self-attention kernel (NULL = off). */
+void dsc_debug_set_self_attn_stamps(void* device_buffer_64B);
 /* Human-readable text for a status code. */
 const char* dsc_status_string(int status);
 

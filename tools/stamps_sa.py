@@ -1,0 +1,17 @@
+"""in-kernel per-segment cycle sums of the flash self-attention loop (workgroup 0, wave 0)"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from diffusionspatialcontrol_amd import ops, _lib
+lib = _lib.load_library(); dev = "cuda"
+buf = torch.zeros(8, dtype=torch.int64, device=dev)
+names = ["issue prefetch loads", "QK^T (6 MFMA + 6 ds_read)", "softmax", "PV (8 MFMA + 16 tr reads)", "wait + LDS write", "barrier"]
+for (B, H, L, d) in [(2, 8, 4096, 40), (2, 8, 1024, 80)]:
+    qkv = torch.randn(B, L, 3 * H * d, device=dev).half(); C = H * d
+    q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+    lib.dsc_debug_set_self_attn_stamps(ctypes.c_void_p(buf.data_ptr()))
+    for _ in range(5): ops.self_attention(q, k, v)
+    torch.cuda.synchronize()
+    lib.dsc_debug_set_self_attn_stamps(None)
+    t = buf.cpu().tolist()[:6]; nt = L // 64
+    print(f"L{L} d{d}: per tile cycles:", " | ".join(f"{n} {x/nt:.0f}" for n, x in zip(names, t)), f"| total/tile {sum(t)/nt:.0f}")
