@@ -297,3 +297,87 @@ def test_sd15_unet_step_full_size(ops):
     scale = outs[0].float().abs().max().item()
     assert (outs[0].float() - outs[1].float()).abs().max().item() < 2e-2 * scale
     assert (plain.float() - outs[0].float()).abs().max().item() > 1e-3       # the region bias is live
+
+
+def _region_tables(levels, S, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    rs = {}
+    for L in levels:
+        w = torch.zeros(2, L, S)
+        m1 = torch.rand(L, generator=g) < 0.3
+        m2 = torch.rand(L, generator=g) < 0.3
+        w[:, m1, 2:4] = 0.5
+        w[:, m2, 4:6] += 0.5
+        rs[L] = w
+    return rs
+
+
+def test_config4_sd15_768_step(ops):
+    """BASELINE configs[3] shape: SD1.5 at 768x768 (L = 9216 / 2304 / 576 / 144), 2 region masks, one CFG step.
+    Region cross-attention at every level is checked against the oracle on the actual q/k/v of that layer (captured
+    with a recording processor), the whole step for finiteness."""
+    from diffusionspatialcontrol_amd.modules.attention_modify import AttnProcessor2_0
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
+    from oracle import region_attention as ra
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        unet = UNet2DConditionModel(UNetConfig.sd15())
+    unet = unet.half().eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 4, 96, 96, generator=g).half().cuda()
+    enc = torch.randn(2, 77, 768, generator=g).half().cuda()
+    t = torch.tensor([700.25, 700.25], device="cuda")
+    rs = _region_tables((9216, 2304, 576, 144), 77)
+    rp = {"region_state": rs, "sigma": torch.tensor([5.0], device="cuda"), "weight_func": lambda w, s, qk: w * s * qk.std()}
+    seen = {}
+
+    class Recorder(AttnProcessor2_0):
+        # region_prompt must be a NAMED parameter: Attention.forward drops kwargs the processor does not declare
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, region_prompt=None):
+            out = super().__call__(attn, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                   region_prompt=region_prompt)
+            L = hidden_states.shape[1]
+            if encoder_hidden_states is not None and L not in seen:
+                q = attn.to_q(hidden_states)
+                k, v = attn.to_k(encoder_hidden_states), attn.to_v(encoder_hidden_states)
+                B, _, C = q.shape
+                H = attn.heads
+                seen[L] = (q.view(B, L, H, C // H), k.view(B, 77, H, C // H), v.view(B, 77, H, C // H),
+                           attn.to_out[0], out)
+            return out
+
+    unet.set_attn_processor(Recorder())
+    with torch.no_grad():
+        y = unet(x, t, enc, cross_attention_kwargs={"region_prompt": rp}).sample
+    assert y.shape == (2, 4, 96, 96) and torch.isfinite(y).all()
+    assert sorted(seen) == [144, 576, 2304, 9216]
+    for L, (q, k, v, to_out, got) in seen.items():
+        qc, kc, vc = (z.float().cpu().transpose(1, 2) for z in (q, k, v))
+        exp = ra.region_attention(qc, kc, vc, rs[L], 5.0)                          # [B, H, L, d] fp32
+        exp = exp.transpose(1, 2).reshape(2, L, -1)
+        exp = torch.nn.functional.linear(exp, to_out.weight.float().cpu(), to_out.bias.float().cpu())
+        err = (got.float().cpu() - exp).abs()
+        assert err.max().item() < 8e-3 * max(1.0, exp.abs().max().item()), (L, err.max().item())
+
+
+def test_config5_sdxl_shape_step(ops):
+    """BASELINE configs[4] shape: SDXL-base UNet geometry (3 levels, transformer depth 0/2/10, 5/10/20 heads of dim
+    64, context dim 2048) at a 1024x1024 latent, region tables at L = 4096 and 1024.  The reference has no SDXL
+    pipeline; this extrapolates the same processor contract.  One CFG step: finite, bias live."""
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
+    torch.manual_seed(0)
+    cfg = UNetConfig.sdxl_base()
+    with torch.device("cuda"):
+        unet = UNet2DConditionModel(cfg).half().eval()
+    assert len(unet.attn_processors) == 140
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 4, 128, 128, generator=g).half().cuda()
+    enc = torch.randn(2, 77, 2048, generator=g).half().cuda()
+    t = torch.tensor([400.0, 400.0], device="cuda")
+    rs = _region_tables((16384, 4096, 1024), 77, seed=2)
+    rp = {"region_state": rs, "sigma": torch.tensor([4.0], device="cuda"), "weight_func": lambda w, s, qk: w * s * qk.std()}
+    with torch.no_grad():
+        y = unet(x, t, enc, cross_attention_kwargs={"region_prompt": rp}).sample
+        y0 = unet(x, t, enc).sample
+    assert y.shape == (2, 4, 128, 128) and torch.isfinite(y).all()
+    assert (y.float() - y0.float()).abs().max().item() > 1e-3
