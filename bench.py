@@ -53,6 +53,9 @@ def parse():
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
                          "falls back to kernels >10x slower on this image; off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode", action="store_true",
+                    help="also run the VAE decoder (SURVEY.md 8f rank 1) inside the timed region; off by default so the "
+                         "headline stays the denoising path of BASELINE.json")
     ap.add_argument("--cpu-sample-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -241,17 +244,26 @@ def main():
     emb = emb.to(dev)
     if dist:                                                    # rank 0's embeddings are THE embeddings
         emb = broadcast_generation_inputs(emb, src=0)
-    pipe = StableDiffusionPipeline(None, None, tok, unet, SD15Scheduler())
+    vae = None
+    if a.decode:
+        from diffusionspatialcontrol_amd.modules.vae_decoder import AutoencoderKLDecoder
+        with torch.device(dev):
+            vae = AutoencoderKLDecoder()
+        vae = vae.half().eval()
+    pipe = StableDiffusionPipeline(vae, None, tok, unet, SD15Scheduler())
     n_img = a.images_per_gpu
     my_images = shard_image_indices(n_img * world, rank, world)
     lat = torch.stack([torch.randn(4, a.size // 8, a.size // 8, generator=torch.Generator().manual_seed(1000 + i))
                        for i in my_images]).half().to(dev)
 
     def generate():
-        return pipe.txt2img(None, height=a.size, width=a.size, num_inference_steps=a.denoise_steps, guidance_scale=7.5,
-                            latents=lat, output_type="latent", region_map_state=state, sampler_name="sample_dpmpp_2m",
-                            sampler_opt={"scheduler": "karras"}, prompt_embeds=emb[1:2], negative_prompt_embeds=emb[0:1],
-                            text_input_ids=ids, num_images_per_prompt=n_img)[0]
+        out = pipe.txt2img(None, height=a.size, width=a.size, num_inference_steps=a.denoise_steps, guidance_scale=7.5,
+                           latents=lat, output_type="latent", region_map_state=state, sampler_name="sample_dpmpp_2m",
+                           sampler_opt={"scheduler": "karras"}, prompt_embeds=emb[1:2], negative_prompt_embeds=emb[0:1],
+                           text_input_ids=ids, num_images_per_prompt=n_img)[0]
+        if a.decode:                                         # pixels stay on the device (decode_latents' .cpu() is host I/O)
+            out = (vae.decode(out / vae.config.scaling_factor).sample / 2 + 0.5).clamp(0, 1)
+        return out
 
     out = None
     for _ in range(a.warmup):
@@ -282,7 +294,7 @@ def main():
             "config": {"workload": f"SD1.5 {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
                                    f"{a.regions} region masks, {n_img} image(s) per GPU per generation",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
-                       "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite},
+                       "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite, "vae_decode_in_timed_region": bool(a.decode)},
         }
         res["roofline"] = roofline_region_xattn(dev, n_img)
         res["roofline_self_attn"] = roofline_self_attn(dev, n_img)

@@ -146,14 +146,36 @@ class StableDiffusionPipeline:
             raise NotImplementedError("SDE samplers are outside the hot path")
         return extra
 
+    @torch.no_grad()
+    def decode_latents(self, latents):
+        """reference :291-299: 1/scaling_factor, vae.decode, /2 + 0.5, clamp, NHWC float32 numpy"""
+        latents = latents.to(self.device, dtype=self.vae.dtype)
+        latents = 1 / self.vae.config.scaling_factor * latents
+        image = self.vae.decode(latents).sample
+        image = (image / 2 + 0.5).clamp(0, 1)
+        return image.cpu().permute(0, 2, 3, 1).float().numpy()
+
+    @staticmethod
+    def numpy_to_pil(images):
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype("uint8")
+        return [Image.fromarray(im) for im in images]
+
     def latent_to_image(self, latents, output_type):
+        """reference :533-539; output_type 'latent' (this build's extra) returns the latents untouched"""
         if output_type == "latent":
             return latents
         if self.vae is None:
-            raise NotImplementedError("VAE decode is the next row after the denoising loop (SURVEY.md 8f rank 1); "
-                                      "pass output_type='latent'")
-        image = self.vae.decode(latents / self.vae.config.scaling_factor, return_dict=False)[0]
-        return image
+            raise NotImplementedError("no VAE was given to the pipeline: pass output_type='latent' or construct it with a "
+                                      "modules.vae_decoder.AutoencoderKLDecoder")
+        image = self.decode_latents(latents)
+        if output_type == "pil":
+            image = self.numpy_to_pil(image)
+        if len(image) > 1:
+            return image
+        return image[0]
 
     # ------------------------------------------------------------------ txt2img
     @torch.no_grad()

@@ -1,0 +1,140 @@
+"""VAE decoder (latents -> RGB) - the step right after the denoising loop, SURVEY.md 8f rank 1.
+
+Counterpart of what reference `source/modules/model_k_diffusion.py` reaches through `self.vae.decode(latents)` in
+`decode_latents` (:291-299) / `latent_to_image` (:533-539): diffusers 0.27.2 `AutoencoderKL` (un-vendored), decoder half
+only.  Structure restated from the published SD1.x VAE (diffusers key names, so `load_state_dict` of the `decoder.*` and
+`post_quant_conv.*` entries of an AutoencoderKL checkpoint works): post_quant_conv 1x1 -> conv_in 4->512 -> mid
+(ResNet, single-head attention over h*w tokens, ResNet) -> 4 up blocks of 3 ResNets (512, 512, 256, 128 channels, nearest
+x2 upsample + conv after the first three) -> GroupNorm + SiLU -> conv_out 128->3.  **Parity unpinned**: diffusers is
+absent; the oracle restatement (oracle/vae_ref.py) shares only the weights.
+
+Device work: channels-last activations; GroupNorm(+SiLU) in libdsc_hip.so (`dsc_groupnorm_silu_nhwc`), 1x1 convs as
+token-major GEMMs, 3x3 convolutions through MIOpen; the single 512-dim attention head (d > 160) goes to torch SDPA, a
+plain library call.
+"""
+from dataclasses import dataclass
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .u_net_condition_modify import Conv1x1, GroupNormAct, _image, _tokens
+
+
+@dataclass
+class VaeConfig:
+    latent_channels: int = 4
+    out_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2                 # the decoder uses layers_per_block + 1 ResNets per up block
+    norm_num_groups: int = 32
+    scaling_factor: float = 0.18215
+
+    @staticmethod
+    def tiny():
+        return VaeConfig(block_out_channels=(32, 32, 64, 64), norm_num_groups=8)
+
+
+class VaeResnet(nn.Module):
+    def __init__(self, cin, cout, groups):
+        super().__init__()
+        self.norm1 = GroupNormAct(groups, cin, 1e-6, act=True)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = GroupNormAct(groups, cout, 1e-6, act=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
+
+    def forward(self, x):
+        h = self.conv2(self.norm2(self.conv1(self.norm1(x))))
+        return self.conv_shortcut(x, residual=h) if self.conv_shortcut is not None else ops.add_bias_residual(x, h)
+
+
+class VaeAttention(nn.Module):
+    """diffusers `Attention(c, heads=1, dim_head=c, norm_num_groups=g, residual_connection=True, bias=True)`"""
+
+    def __init__(self, c, groups):
+        super().__init__()
+        self.group_norm = GroupNormAct(groups, c, 1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        t = _tokens(self.group_norm(x))
+        q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
+        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]        # one head of dim c
+        return _image(ops.linear(o, self.to_out[0].weight, self.to_out[0].bias, residual=_tokens(x)), h, w)
+
+
+class _Mid(nn.Module):
+    def __init__(self, c, groups):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(c, c, groups), VaeResnet(c, c, groups)])
+        self.attentions = nn.ModuleList([VaeAttention(c, groups)])
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, n, groups, upsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        if upsample:
+            self.upsamplers = nn.ModuleList([nn.ModuleDict({"conv": nn.Conv2d(cout, cout, 3, padding=1)})])
+
+
+class Decoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        ch = list(reversed(cfg.block_out_channels))
+        self.conv_in = nn.Conv2d(cfg.latent_channels, ch[0], 3, padding=1)
+        self.mid_block = _Mid(ch[0], cfg.norm_num_groups)
+        self.up_blocks = nn.ModuleList()
+        prev = ch[0]
+        for i, c in enumerate(ch):
+            self.up_blocks.append(_Up(prev, c, cfg.layers_per_block + 1, cfg.norm_num_groups, i < len(ch) - 1))
+            prev = c
+        self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[-1], 1e-6, act=True)
+        self.conv_out = nn.Conv2d(ch[-1], cfg.out_channels, 3, padding=1)
+
+
+class _Cfg(dict):
+    __getattr__ = dict.get
+
+
+class AutoencoderKLDecoder(nn.Module):
+    """`vae.decode(latents).sample` of the reference pipeline (decoder half of AutoencoderKL)."""
+
+    def __init__(self, cfg: VaeConfig = None):
+        super().__init__()
+        cfg = cfg or VaeConfig()
+        self.cfg = cfg
+        self.config = _Cfg(scaling_factor=cfg.scaling_factor, block_out_channels=cfg.block_out_channels)
+        self.post_quant_conv = Conv1x1(cfg.latent_channels, cfg.latent_channels)
+        self.decoder = Decoder(cfg)
+        self._channels_last = False
+
+    @property
+    def dtype(self):
+        return self.decoder.conv_in.weight.dtype
+
+    def decode(self, z, return_dict=True):
+        d = self.decoder
+        if not self._channels_last:
+            self.to(memory_format=torch.channels_last)
+            for conv in (d.conv_in, d.conv_out):                 # 4 / 3 channels: no NHWC igemm in MIOpen, run NCHW
+                conv.weight.data = conv.weight.data.contiguous()
+            self._channels_last = True
+        b, c, h, w = z.shape
+        z = F.conv2d(z.contiguous(), self.post_quant_conv.weight, self.post_quant_conv.bias)
+        x = d.conv_in(z).contiguous(memory_format=torch.channels_last)
+        x = d.mid_block.resnets[0](x)
+        x = d.mid_block.attentions[0](x)
+        x = d.mid_block.resnets[1](x)
+        for blk in d.up_blocks:
+            for res in blk.resnets:
+                x = res(x)
+            if hasattr(blk, "upsamplers"):
+                x = blk.upsamplers[0]["conv"](F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        x = d.conv_out(d.conv_norm_out(x).contiguous()).contiguous()
+        return type("DecoderOutput", (), {"sample": x})() if return_dict else (x,)
