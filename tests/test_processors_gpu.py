@@ -1,0 +1,176 @@
+"""GPU parity of the drop-in processors against the outputs of the REFERENCE's own processors
+(tests/golden/processors.npz, captured by tests/golden/make_golden.py), and size-independent properties of the
+region cross-attention at the full bench shape (Bc=2, H=8, L=4096, S=77, d=40)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from inputs import attn_inputs, proc_inputs
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 6e-3          # fp16 projections + fp16 attention output vs the reference's fp32 CPU run
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from diffusionspatialcontrol_amd import ops
+    from diffusionspatialcontrol_amd.modules import attention_modify as am
+    return ops, am
+
+
+class DuckAttn:
+    """the attributes the processors touch, fp16 on the GPU"""
+
+    def __init__(self, p, residual_connection=False, rescale=1.0, self_kv=False):
+        C, H = p["C"], p["H"]
+        self.heads, self.scale = H, (C // H) ** -0.5
+        self.spatial_norm = self.group_norm = self.norm_cross = None
+        self.residual_connection, self.rescale_output_factor = residual_connection, rescale
+        self.upcast_attention = self.upcast_softmax = False
+
+        def lin(w, b=None):
+            m = nn.Linear(w.shape[1], w.shape[0], bias=b is not None)
+            m.weight.data = torch.from_numpy(w)
+            if b is not None:
+                m.bias.data = torch.from_numpy(b)
+            return m.half().cuda()
+
+        self.to_q = lin(p["wq"])
+        self.to_k = lin(p["wk_self"] if self_kv else p["wk"])
+        self.to_v = lin(p["wv_self"] if self_kv else p["wv"])
+        self.to_out = nn.ModuleList([lin(p["wo"], p["bo"]), nn.Dropout(0.0)])
+
+
+@pytest.mark.parametrize("pname", ["p2", "p1"])
+def test_processors_against_reference_goldens(mods, pname):
+    ops, am = mods
+    g = np.load(os.path.join(G, "processors.npz"))
+    p = proc_inputs()
+    L = p["L"]
+    proc = am.AttnProcessor2_0() if pname == "p2" else am.AttnProcessor()
+    hs, enc = torch.from_numpy(p["hidden"]).half().cuda(), torch.from_numpy(p["enc"]).half().cuda()
+    wf = lambda w, sigma, qk: w * sigma * qk.std()       # noqa: E731  (app.py:1004)
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": torch.tensor(2.5), "weight_func": wf}
+    attn = DuckAttn(p)
+
+    def check(out, key):
+        err = np.abs(out.float().cpu().numpy() - g[f"{pname}/{key}"])
+        assert err.max() < TOL, (key, err.max())
+
+    with torch.no_grad():
+        check(proc(attn, hs, encoder_hidden_states=enc, region_prompt=rp), "cross_region")
+        check(proc(attn, hs, encoder_hidden_states=enc), "cross_noregion")
+        rp_nd = dict(rp, region_state=torch.FloatTensor(0))
+        check(proc(attn, hs, encoder_hidden_states=enc, region_prompt=rp_nd), "cross_nondict")
+        check(proc(DuckAttn(p, self_kv=True), hs, region_prompt=rp), "self")
+        h = int(math.isqrt(L))
+        hs4 = hs.transpose(1, 2).reshape(2, p["C"], h, h).contiguous()
+        rp4 = dict(rp, region_state={p["C"]: torch.from_numpy(p["w"])})      # keyed by shape[1] == C for 4-D input (:427)
+        check(proc(DuckAttn(p, True, 2.0), hs4, encoder_hidden_states=enc, region_prompt=rp4), "cross_region_4d_res")
+        with pytest.raises(KeyError):
+            proc(attn, hs, encoder_hidden_states=enc, region_prompt=dict(rp, region_state={L + 1: torch.from_numpy(p["w"])}))
+        with pytest.raises(NotImplementedError):
+            proc(attn, hs, encoder_hidden_states=enc, attention_mask=torch.zeros(1), region_prompt=rp)
+
+
+def test_custom_weight_func_takes_the_generic_path(mods):
+    """a caller-supplied weight_func that is NOT w*sigma*std: evaluated as the reference would, result added by the kernel"""
+    ops, am = mods
+    p = proc_inputs()
+    L = p["L"]
+    hs, enc = torch.from_numpy(p["hidden"]).half().cuda(), torch.from_numpy(p["enc"]).half().cuda()
+    wf = lambda w, sigma, qk: w * sigma * qk.abs().max() * 0.1      # noqa: E731
+    assert not am.weight_func_is_default(wf)
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": torch.tensor(2.5), "weight_func": wf}
+    attn = DuckAttn(p)
+    with torch.no_grad():
+        out = am.AttnProcessor2_0()(attn, hs, encoder_hidden_states=enc, region_prompt=rp).float().cpu()
+    # fp32 restatement with the same callable
+    hs32, enc32 = torch.from_numpy(p["hidden"]), torch.from_numpy(p["enc"])
+    q = hs32 @ torch.from_numpy(p["wq"]).t()
+    k, v = enc32 @ torch.from_numpy(p["wk"]).t(), enc32 @ torch.from_numpy(p["wv"]).t()
+    H, d = p["H"], p["C"] // p["H"]
+    q4, k4, v4 = (t.view(2, -1, H, d).transpose(1, 2) for t in (q, k, v))
+    a = (q4 @ k4.transpose(-2, -1)) / math.sqrt(d)
+    flat = a.reshape(-1, L, 77)
+    cw = wf(torch.from_numpy(p["w"]), torch.tensor(2.5), flat)
+    flat = flat + torch.repeat_interleave(cw, flat.shape[0] // cw.shape[0], dim=0)
+    o = (torch.softmax(flat.reshape(2, H, L, 77), -1) @ v4).transpose(1, 2).reshape(2, L, -1)
+    ref = o @ torch.from_numpy(p["wo"]).t() + torch.from_numpy(p["bo"])
+    assert (out - ref).abs().max().item() < 1.2e-2      # the callable sees fp16 scores (max is 1 fp16 ulp off)
+
+
+def test_region_attention_function_signature(mods):
+    """`scaled_dot_product_attention_regionstate(query, key, value, ..., weight_func, region_state, sigma)` drop-in"""
+    ops, am = mods
+    g = np.load(os.path.join(G, "attention_core.npz"))
+    x = attn_inputs("L256_d160", Bc=2, H=8, L=256, S=77, d=160)
+    q, k, v = (torch.from_numpy(x[n]).half().cuda() for n in ("q", "k", "v"))
+    out = am.scaled_dot_product_attention_regionstate(q, k, v, weight_func=lambda w, s, qk: w * s * qk.std(),
+                                                      region_state=torch.from_numpy(x["w"]), sigma=torch.tensor(3.25))
+    err = np.abs(out[:, :, x["rows"], :].float().cpu().numpy() - g["L256_d160/out_rows"])
+    assert err.max() < 8e-3                              # fp16-rounding emulation on: |scores + bias| reaches ~10 here
+
+
+# ---------------------------------------------------------------------------- properties at the full bench shape
+@pytest.fixture(scope="module")
+def full(mods):
+    ops, _ = mods
+    Bc, H, L, S, d = 2, 8, 4096, 77, 40
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(Bc, L, H, d, generator=g).half().cuda()
+    k = torch.randn(Bc, S, H, d, generator=g).half().cuda()
+    v = torch.randn(Bc, S, H, d, generator=g).half().cuda()
+    w = torch.zeros(2, L, S)
+    w[:, 500:2000, 2:4] = 0.5
+    w[:, 1500:3500, 4:6] += 0.75
+    return ops, q, k, v, w
+
+
+def _run(ops, q, k, v, w, sigma=4.0, packed=True):
+    if packed:
+        pk = ops.xattn_kv_pack(k, v)
+        comp = ops.compress_region_table(w.cuda()) if w is not None else None
+        return ops.region_xattn_packed(q, pk, k.shape[1], comp, sigma, ref_fp16_rounding=False)
+    return ops.region_xattn(q, k, v, None if w is None else w.cuda(), sigma, layout="blhd", ref_fp16_rounding=False)
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_rows_are_convex_combinations(full, packed):
+    """softmax rows sum to one: V = 1 gives 1; V = c per channel gives c (both kernels, full size)"""
+    ops, q, k, v, w = full
+    ones = torch.ones_like(v)
+    out = _run(ops, q, k, ones, w, packed=packed).float()
+    assert (out - 1.0).abs().max().item() < 2e-3
+    ramp = (torch.arange(v.shape[-1], device="cuda").half() / 8).expand_as(v).contiguous()
+    out = _run(ops, q, k, ramp, w, packed=packed).float()
+    assert (out - ramp[0, 0, 0].float()).abs().max().item() < 4e-3
+
+
+def test_linear_in_v_and_key_permutation_invariant(full):
+    ops, q, k, v, w = full
+    g = torch.Generator(device="cuda").manual_seed(5)
+    v2 = torch.randn(v.shape, generator=g, device="cuda").half()
+    o1, o2 = _run(ops, q, k, v, w).float(), _run(ops, q, k, v2, w).float()
+    o12 = _run(ops, q, k, (v.float() + v2.float()).half(), w).float()
+    assert (o12 - (o1 + o2)).abs().max().item() < 6e-3
+    perm = torch.randperm(77, generator=torch.Generator().manual_seed(2))
+    op = _run(ops, q, k[:, perm.cuda()].contiguous(), v[:, perm.cuda()].contiguous(), w[:, :, perm].contiguous()).float()
+    assert (op - o1).abs().max().item() < 3e-3        # fp16 P: summation order inside the MFMA changes
+
+
+def test_sigma_zero_and_zero_table_equal_plain_attention(full):
+    ops, q, k, v, w = full
+    plain = _run(ops, q, k, v, None).float()
+    assert (_run(ops, q, k, v, w, sigma=0.0).float() - plain).abs().max().item() < 1e-3
+    assert (_run(ops, q, k, v, torch.zeros_like(w), sigma=9.0).float() - plain).abs().max().item() < 1e-3
+    assert torch.equal(_run(ops, q, k, v, w), _run(ops, q, k, v, w))            # idempotent / bit-reproducible
+    # a bias that is constant along the keys of a row cancels in the softmax
+    const = torch.full_like(w, 0.3)
+    assert (_run(ops, q, k, v, const, sigma=2.0).float() - plain).abs().max().item() < 2e-3
