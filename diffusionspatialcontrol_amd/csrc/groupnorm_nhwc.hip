@@ -124,6 +124,71 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     }
 }
 
+// Small images (the 8x8 / 16x16 UNet levels): ONE launch, one workgroup per (image, group).  The group's slab
+// (hw pixels x cpg channels, cpg % 8 == 0, at most kSmallVec 16-byte vectors per thread) is read once into registers,
+// reduced (two-pass variance on the register copy), normalised and written - instead of three launches of ~3 us each.
+constexpr int kSmallVec = 8;
+__global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
+    __shared__ float red[8];
+    const int b = blockIdx.x / p.G, g = blockIdx.x % p.G;
+    const int vpp = p.cpg >> 3;                               // vectors per pixel of this group
+    const int nvec = p.HW * vpp;
+    const long long base = (long long)b * p.HW * p.C + g * p.cpg;
+    float v[kSmallVec][8];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSmallVec; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < nvec) {
+            const int pix = idx / vpp, j8 = idx - pix * vpp;
+            const h8_t x = *reinterpret_cast<const h8_t*>(p.x + base + (long long)pix * p.C + j8 * 8);
+            h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + g * p.cpg + j8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = (float)x[j] + (float)ad[j]; s1 += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s1 = wave_sum_f32(s1);
+    if (lane == 0) red[wave] = s1;
+    __syncthreads();
+    const float n = (float)p.HW * p.cpg;
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / n;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kSmallVec; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < nvec) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dlt = v[i][j] - mean; s2 += dlt * dlt; }
+        }
+    }
+    s2 = wave_sum_f32(s2);
+    if (lane == 0) red[4 + wave] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / n + p.eps);
+#pragma unroll
+    for (int i = 0; i < kSmallVec; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        if (idx < nvec) {
+            const int pix = idx / vpp, j8 = idx - pix * vpp;
+            const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + g * p.cpg + j8 * 8);
+            const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + g * p.cpg + j8 * 8);
+            h8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (v[i][j] - mean) * rstd * (float)ga[j] + (float)be[j];
+                if (p.silu) f = f / (1.f + __expf(-f));
+                o[j] = (half_t)f;
+            }
+            *reinterpret_cast<h8_t*>(p.y + base + (long long)pix * p.C + j8 * 8) = o;
+        }
+    }
+}
+
 bool plan(GnN& p) {
     p.cv = p.C / 8;
     if (p.C % 8 != 0 || p.cv > kMaxT || p.G > 64 || p.C % p.G != 0) return false;
@@ -200,6 +265,10 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     p.stats = reinterpret_cast<float*>(p.partials + (size_t)B * p.nchunk * groups * 2);
     p.eps = eps; p.silu = apply_silu;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p.cpg % 8 == 0 && (long long)p.HW * (p.cpg / 8) <= 256 * kSmallVec) {      // small image: single launch
+        hipLaunchKernelGGL(gn_nhwc_small, dim3(B * groups), dim3(256), 0, st, p);
+        return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+    }
     const dim3 grid(B * p.nchunk), block(p.cv * p.k);
     hipLaunchKernelGGL(gn_nhwc_stats, grid, block, (size_t)2 * p.k * C * sizeof(float), st, p);
     hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B), dim3(256), 0, st, p);

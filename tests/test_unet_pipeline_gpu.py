@@ -41,7 +41,9 @@ def test_groupnorm_silu(ops, B, C, h, w, G, act, eps):
 @pytest.mark.parametrize("B,C,h,w,G,act,with_add", [(2, 320, 64, 64, 32, True, True), (2, 2560, 16, 16, 32, True, False),
                                                     (2, 1280, 8, 8, 32, False, False), (1, 32, 2, 2, 8, True, True),
                                                     (16, 640, 32, 32, 32, True, True), (3, 64, 5, 3, 8, False, True),
-                                                    (2, 1920, 32, 32, 32, True, False), (2, 960, 64, 64, 32, True, True)])
+                                                    (2, 1920, 32, 32, 32, True, False), (2, 960, 64, 64, 32, True, True),
+                                                    (2, 2560, 8, 8, 32, True, True), (2, 1280, 16, 16, 32, True, True),
+                                                    (2, 2560, 16, 16, 32, True, False), (4, 1280, 8, 8, 32, False, True)])
 def test_groupnorm_silu_nhwc(ops, B, C, h, w, G, act, with_add):
     g = torch.Generator().manual_seed(B * C + h + 1)
     x = (torch.randn(B, C, h, w, generator=g) * 1.7 + 0.6).half()
