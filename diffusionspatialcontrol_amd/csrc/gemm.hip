@@ -14,8 +14,10 @@
 //     D^T[n, m] = W[n, :] . X[m, :]  on v_mfma_f32_32x32x16_f16 (A = W rows, B = X^T), so a lane owns one token row m
 //     with 4 consecutive output channels per register group;
 //   * tiles (128 tokens x 64 channels x 64 K) go HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR staging); the
-//     LDS image is lane-linear, so the bank-conflict XOR swizzle (16-byte chunk ^= row & 7) is applied to the per-lane
-//     SOURCE address and again on the ds_read_b128 address (guide rule 21);
+//     LDS image is lane-linear, so the bank-conflict XOR swizzle (16-byte chunk ^= (row >> 1) & 7: a 128-byte row covers
+//     half of the 64 banks, the half being the row parity, so the 16 rows {0-3,12-15,20-27} a ds_read_b128 lane group
+//     touches get 16 distinct (parity, chunk) pairs) is applied to the per-lane SOURCE address and again on the
+//     ds_read_b128 address (guide rule 21);
 //   * a ring of STAGES LDS buffers: STAGES-1 K tiles are in flight by DMA while one is multiplied; a counted
 //     `s_waitcnt vmcnt(6*(STAGES-2))` + a RAW s_barrier publish tile t without draining the younger DMAs
 //     (__syncthreads() would wait vmcnt(0)); the refill of a buffer is issued right after the barrier that proves every
@@ -38,7 +40,7 @@ struct GemmParams {
     long long ldx, ldr, ldo;     // row strides (elements) of x, residual, out
 };
 
-// DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^(row&7)
+// DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
 template <int ROWS>
 __device__ __forceinline__ void dma_tile(const half_t* g, long long ld, int row0, int rows_valid, int k0, half_t* lds,
                                          int wave, int lane) {
@@ -47,7 +49,7 @@ __device__ __forceinline__ void dma_tile(const half_t* g, long long ld, int row0
         const int piece = pc * 4 + wave;
         const int row = piece * 8 + (lane >> 3);
         const int grow = min(row0 + row, rows_valid - 1);
-        const int chunk = (lane & 7) ^ (row & 7);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         const half_t* src = g + (long long)grow * ld + k0 + chunk * 8;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(lds + piece * 512), 16, 0, 0);
@@ -55,7 +57,7 @@ __device__ __forceinline__ void dma_tile(const half_t* g, long long ld, int row0
 }
 
 __device__ __forceinline__ h8_t lds_frag(const half_t* tile, int row, int kchunk) {
-    return *reinterpret_cast<const h8_t*>(tile + row * BK + ((kchunk ^ (row & 7)) << 3));
+    return *reinterpret_cast<const h8_t*>(tile + row * BK + ((kchunk ^ ((row >> 1) & 7)) << 3));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
                 const int piece = pc * 4 + wave;             // 8 pieces of 8 rows
                 const int row = piece * 8 + (lane >> 3);
                 const int grow = (row < 32 ? n0 + row : Nh + n0 + row - 32);
-                const int chunk = (lane & 7) ^ (row & 7);
+                const int chunk = (lane & 7) ^ ((row >> 1) & 7);
                 const half_t* src = p.w + (long long)grow * p.K + kt * BK + chunk * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(b + piece * 512), 16, 0, 0);

@@ -262,6 +262,18 @@ class Transformer2DModel(nn.Module):
         return _image(t, h, w)
 
 
+def _conv3x3(x, weight, bias=None, residual=None):
+    """3x3 / pad 1 convolution (+ bias) (+ residual): dsc_conv3x3_nhwc_f16 where it covers the shape (channels-last fp16,
+    channel counts that are multiples of 64, 8-aligned image sides), otherwise the library convolution (MIOpen) with
+    the separate fused add."""
+    if ops.conv3x3_supported(x, weight):
+        return ops.conv3x3(x, weight, bias, residual)
+    h = F.conv2d(x, weight, None, padding=1)
+    if residual is not None:
+        return ops.add_bias_residual(residual, h, bias)
+    return h if bias is None else h + bias.view(1, -1, 1, 1)
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, cin, cout, temb_dim, groups, eps):
         super().__init__()
@@ -280,12 +292,12 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb_act, temb_add=None):
         # conv biases never run as separate MIOpen bias kernels: conv1's is folded into the time-embedding term (which
         # is itself folded into norm2's load), conv2's into the shortcut GEMM's bias or the fused residual add
-        h = F.conv2d(self.norm1(x), self.conv1.weight, None, padding=1)
+        h = _conv3x3(self.norm1(x), self.conv1.weight)
         if temb_add is None:
             temb_add = F.linear(temb_act, self.time_emb_proj.weight, self.temb_bias())
-        h = F.conv2d(self.norm2(h, add=temb_add), self.conv2.weight, None, padding=1)
         if self.conv_shortcut is None:
-            return ops.add_bias_residual(x, h, self.conv2.bias)
+            return _conv3x3(self.norm2(h, add=temb_add), self.conv2.weight, self.conv2.bias, residual=x)
+        h = _conv3x3(self.norm2(h, add=temb_add), self.conv2.weight)
         b = _derived(self, "sb", (self.conv_shortcut.bias, self.conv2.bias),
                      lambda: (self.conv_shortcut.bias + self.conv2.bias).contiguous())
         bsz, _, hh, ww = h.shape
@@ -307,6 +319,8 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x):
+        if ops.conv3x3_supported(x, self.conv.weight, upsample=True):      # the upsampling happens in the halo gather
+            return ops.conv3x3(x, self.conv.weight, self.conv.bias, upsample=True)
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 

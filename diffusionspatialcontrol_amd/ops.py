@@ -311,6 +311,53 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
     return out.reshape(*lead, n_out)
 
 
+USE_DSC_CONV = True        # route qualifying 3x3 convolutions to dsc_conv3x3_nhwc_f16 (False: always MIOpen through torch)
+
+
+def conv3x3_supported(x, weight, upsample=False):
+    """True when dsc_conv3x3_nhwc_f16 covers this [B, Cin, H, W] channels_last fp16 input / [Cout, Cin, 3, 3] weight
+    (upsample: the convolution runs on the 2x nearest-upsampled image)."""
+    if not (USE_DSC_CONV and x.is_cuda and x.dtype == torch.float16 and weight.dtype == torch.float16 and x.dim() == 4
+            and tuple(weight.shape[2:]) == (3, 3) and weight.shape[1] == x.shape[1]):
+        return False
+    B, C, H, W = x.shape
+    f = 2 if upsample else 1
+    return bool(_lib.load_library().dsc_conv3x3_supported(B, H * f, W * f, C, weight.shape[0]))
+
+
+def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False):
+    """3x3 / stride 1 / pad 1 convolution (+ bias) (+ residual) of a channels_last fp16 [B, Cin, H, W] tensor with a
+    [Cout, Cin, 3, 3] weight held in channels_last memory format (dsc_conv3x3_nhwc_f16); returns channels_last
+    [B, Cout, H, W].  upsample=True convolves the 2x nearest-neighbour upsampling of x (output [B, Cout, 2H, 2W]) without
+    materialising it.  Raises on an unsupported shape - ask conv3x3_supported() first."""
+    _require_gpu(x, weight)
+    lib = _lib.load_library()
+    cl = torch.channels_last
+    if not x.is_contiguous(memory_format=cl):
+        x = x.contiguous(memory_format=cl)
+    if not weight.is_contiguous(memory_format=cl):
+        weight = weight.contiguous(memory_format=cl)
+    B, Cin, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
+    Cout = weight.shape[0]
+    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+    ldr = 0
+    if residual is not None:
+        if residual.shape != out.shape:
+            raise ValueError("conv3x3: residual must have the output's shape")
+        if not residual.is_contiguous(memory_format=cl):
+            residual = residual.contiguous(memory_format=cl)
+        ldr = Cout
+    nbytes = lib.dsc_conv3x3_workspace_bytes(B, H, W, Cin, Cout, splits)
+    ws = _workspace(x.device, nbytes) if nbytes else None
+    rc = lib.dsc_conv3x3_nhwc_f16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, Cin, ldr, Cout,
+                                  1 if upsample else 0, splits, 0, _p(ws), ws.numel() * 8 if ws is not None else 0,
+                                  _stream_ptr(x))
+    _lib.check(rc, "dsc_conv3x3_nhwc_f16")
+    return out
+
+
 def add_bias_residual(a, b, bias=None):
     """a + b + bias[c] over channels-last / token-major fp16 tensors of identical layout (dsc_add_bias_residual)."""
     _require_gpu(a, b)

@@ -212,6 +212,31 @@ int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* r
                    int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu, int dtype, void* stream);
 
 /*
+ * 3x3 / stride 1 / pad 1 convolution over channels-last fp16 - replaces `F.conv2d` (MIOpen) for the ResnetBlock2D
+ * conv1/conv2 and the Upsample2D conv of the UNet that reference source/modules/u_net_condition_modify.py assembles
+ * from diffusers blocks:
+ *   out[b,y,x,n] = sum_{dy,dx,c} x[b,y+dy-1,x+dx-1,c] * w[n,dy,dx,c]  (+ bias[n]) (+ residual[b,y,x,n]),  zero padding
+ * x [B,H,W,Cin] with pixel stride ldx, w [Cout,3,3,Cin] contiguous (a torch conv weight in channels_last memory
+ * format), residual / out [B,H,W,Cout] with pixel strides ldr / ldo.  fp32 accumulation, one fp16 rounding.
+ * upsample2x != 0: x is [B,H/2,W/2,Cin] and the convolution reads it through a nearest-neighbour 2x upsampling
+ * (diffusers Upsample2D = F.interpolate(scale_factor=2, mode="nearest") + conv) without materialising the upsampled image.
+ * splits: number of input-channel ranges accumulated by separate workgroups (0 = chosen from the shape); splits > 1
+ * needs `workspace` (dsc_conv3x3_workspace_bytes) and sums the partials in range order: bit-reproducible.
+ * Supported (dsc_conv3x3_supported): Cin % 64 == 0, Cout % 64 == 0, H % 8 == 0, W % 8 == 0, strides % 8 == 0, 16-byte
+ * aligned pointers; anything else returns DSC_ERR_UNSUPPORTED and the caller keeps the library convolution.
+ */
+int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
+/* diagnostics: 8 x int64 per workgroup (start / loop start / loop end / end in 100 MHz ticks, the three segment lengths in
+ * shader clocks, XCC and HW ids) of every following dsc_conv3x3_nhwc_f16 call go to `device_buffer`; NULL switches it off */
+void dsc_debug_set_conv_stamps(void* device_buffer);
+/* diagnostics: force the weight-tile ring depth (3, 6 or 10 stages); 0 = chosen from the grid size */
+void dsc_debug_set_conv_ring(int stages);
+size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
+int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                         int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
+                         int upsample2x, int splits, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * (residual add +) LayerNorm over the last dimension - replaces the `x = attn(...) + x` elementwise add and the
  * `nn.LayerNorm` that follows it in diffusers' BasicTransformerBlock (norm1/norm2/norm3, eps 1e-5):
  *   s[r, :]  = x[r, :] + a[r, :]            (a == NULL: s = x)         -> written to `sum_out` when non-NULL (fp16)

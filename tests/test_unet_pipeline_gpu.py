@@ -120,6 +120,72 @@ def test_linear_kernel(ops, M, N, K):
     assert torch.all((o3.float().cpu() - ref3).abs() <= 1.5e-3 * ref3.abs() + 2e-3)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,splits", [
+    (2, 320, 320, 64, 64, 0), (2, 640, 320, 64, 64, 0), (2, 640, 640, 32, 32, 0), (2, 640, 640, 32, 32, 1),
+    (2, 1920, 640, 32, 32, 0), (2, 1280, 1280, 16, 16, 0), (2, 2560, 1280, 16, 16, 0), (2, 1280, 1280, 8, 8, 0),
+    (2, 2560, 1280, 8, 8, 0), (1, 64, 64, 8, 8, 0), (3, 128, 64, 8, 8, 2), (1, 64, 128, 16, 24, 0), (2, 192, 64, 24, 48, 3),
+    (1, 320, 320, 96, 96, 0), (5, 64, 64, 8, 16, 0)])
+def test_conv3x3_kernel(ops, B, Cin, Cout, H, W, splits):
+    """dsc_conv3x3_nhwc_f16 vs an fp32 convolution on fp16-representable operands (one fp16 rounding of the fp32 sum):
+    image borders (zero padding), 16- and 8-wide tiles, ragged last tile, split input-channel ranges, bias + residual."""
+    g = torch.Generator().manual_seed(B * 7 + Cin + Cout + H + W)
+    cl = torch.channels_last
+    x = torch.randn(B, Cin, H, W, generator=g).half()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half()
+    b = (torch.randn(Cout, generator=g) * 0.2).half()
+    r = torch.randn(B, Cout, H, W, generator=g).half()
+    xd, wd = x.cuda().contiguous(memory_format=cl), w.cuda().contiguous(memory_format=cl)
+    bd, rd = b.cuda(), r.cuda().contiguous(memory_format=cl)
+    assert ops.conv3x3_supported(xd, wd)
+    ref = F.conv2d(xd.float(), wd.float(), bd.float(), padding=1).cpu()
+    out = ops.conv3x3(xd, wd, bd, splits=splits)
+    assert out.shape == (B, Cout, H, W) and out.is_contiguous(memory_format=cl)
+    err = (out.float().cpu() - ref).abs()
+    assert torch.all(err <= 1.5e-3 * ref.abs() + 2e-3), err.max().item()
+    out_r = ops.conv3x3(xd, wd, bd, residual=rd, splits=splits)
+    ref_r = ref + r.float()
+    assert torch.all((out_r.float().cpu() - ref_r).abs() <= 1.5e-3 * ref_r.abs() + 2e-3)
+    out_n = ops.conv3x3(xd, wd, None, splits=splits)
+    ref_n = ref - b.float().view(1, -1, 1, 1)
+    assert torch.all((out_n.float().cpu() - ref_n).abs() <= 1.5e-3 * ref_n.abs() + 2e-3)
+    assert torch.equal(out, ops.conv3x3(xd, wd, bd, splits=splits))          # bit-reproducible, split or not
+    # a localised impulse: every tap lands where it should (catches halo / tap-offset indexing independent of tolerance)
+    xi = torch.zeros(B, Cin, H, W).half()
+    xi[B - 1, 5, H - 1, 0] = 1.0
+    xi[0, Cin - 1, 3, W - 1] = 2.0
+    oi = ops.conv3x3(xi.cuda().contiguous(memory_format=cl), wd, None, splits=splits).float().cpu()
+    ri = F.conv2d(xi.float(), w.float(), None, padding=1)
+    assert torch.all((oi - ri).abs() <= 1e-3 * ri.abs() + 1e-6)
+
+
+@pytest.mark.parametrize("B,C,Cout,h,w", [(2, 1280, 1280, 8, 8), (2, 640, 640, 32, 32), (1, 64, 64, 4, 12), (3, 128, 64, 4, 4)])
+def test_conv3x3_upsample(ops, B, C, Cout, h, w):
+    """Upsample2D: nearest 2x + conv (diffusers) == the convolution reading the small image through the upsampling map"""
+    g = torch.Generator().manual_seed(B + C + h + w)
+    cl = torch.channels_last
+    x = torch.randn(B, C, h, w, generator=g).half().cuda().contiguous(memory_format=cl)
+    wt = (torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)).half().cuda().contiguous(memory_format=cl)
+    b = (torch.randn(Cout, generator=g) * 0.2).half().cuda()
+    assert ops.conv3x3_supported(x, wt, upsample=True)
+    out = ops.conv3x3(x, wt, b, upsample=True)
+    up = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(up.float(), wt.float(), b.float(), padding=1)
+    assert out.shape == (B, Cout, 2 * h, 2 * w)
+    assert torch.all((out.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3)
+    assert torch.equal(out, ops.conv3x3(up, wt, b))                        # same sums in the same order
+
+
+def test_conv3x3_unsupported(ops):
+    x = torch.randn(1, 4, 64, 64).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(320, 4, 3, 3).half().cuda().contiguous(memory_format=torch.channels_last)
+    assert not ops.conv3x3_supported(x, w)
+    with pytest.raises(Exception):
+        ops.conv3x3(x, w)
+    x2 = torch.randn(1, 64, 12, 12).half().cuda().contiguous(memory_format=torch.channels_last)
+    w2 = torch.randn(64, 64, 3, 3).half().cuda().contiguous(memory_format=torch.channels_last)
+    assert not ops.conv3x3_supported(x2, w2)
+
+
 @pytest.mark.parametrize("M,C", [(8192, 320), (2048, 640), (512, 1280), (300, 64)])
 def test_linear_geglu_kernel(ops, M, C):
     g = torch.Generator().manual_seed(M + C)
