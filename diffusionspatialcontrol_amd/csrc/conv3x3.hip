@@ -21,18 +21,20 @@
 //   epilogue   through an fp32 LDS stage: + bias (+ residual), one fp16 rounding, 128-byte row segments
 #include "dsc_common.h"
 #include "dsc_hip.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int BM = 128, BN = 64, BK = 64, T = 256;
-constexpr int kBStage = BN * BK;                 // halves per weight tile (8 KiB)
+constexpr int kBStageBytes = BN * BK * 2;        // one weight tile: 8 KiB
+constexpr int kStages = 3;                       // ring depth; 9 taps % 3 == 0 makes a tile's stage its tap % 3: compile-time
 constexpr int kAPiecesMax = 25;                  // 200 halo slots
-constexpr int kAHalves = kAPiecesMax * 512;      // one halo buffer: 25.6 KiB
-constexpr int kDummy = 512;                      // landing pad for the DMA pieces beyond the halo (keeps vmcnt uniform)
-constexpr int lds_halves(int stages) { return 2 * kAHalves + kDummy + stages * kBStage; }   // 3 stages: 75 KiB -> 2 workgroups / CU
+constexpr int kABytes = kAPiecesMax * 1024;      // one halo buffer: 25 KiB
+// LDS map (bytes): weight ring | halo buffer 0 | halo buffer 1 | landing pad for the DMA pieces beyond the halo
+constexpr int kRingOff = 0, kAOff = kStages * kBStageBytes, kPadOff = kAOff + 2 * kABytes;
+constexpr int kLdsBytes = kPadOff + 1024;        // 76800 B -> two workgroups per CU
 constexpr int kEpiStride = BN + 4;
-
-__device__ __attribute__((aligned(16))) half_t g_zero_page[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+constexpr unsigned kOob = 0x80000000u;           // buffer offset beyond any supported tensor: the load returns zeros
 
 struct ConvParams {
     const half_t* x; const half_t* w; const half_t* bias; const half_t* res; half_t* out; float* ws;
@@ -43,12 +45,14 @@ struct ConvParams {
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
     int mt, nt;                   // tiles along pixels / output channels
     long long npix;
+    unsigned x_bytes, w_bytes;    // extents for the buffer descriptors
     long long* stamps;            // diagnostics (dsc_debug_set_conv_stamps): 8 x int64 per workgroup, NULL in normal calls
 };
 
-__device__ __forceinline__ void dma16(const half_t* src, half_t* dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+// LDS-DMA of 16 bytes per lane through a buffer descriptor: lanes whose offset lies beyond the extent deposit zeros -
+// the convolution's zero padding costs no branch and no memory traffic
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_byte) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, soff, 0, 0);
 }
 
 // s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their no-wait maxima); gfx9 simm16: vmcnt[3:0] | exp[6:4] | lgkm[11:8] | vmcnt[5:4] << 14
@@ -59,29 +63,11 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("" ::: "memory");
 }
 
-// DMA instructions a wave issues after weight tile j+1 (the last thing step j+1-S issued) up to step j-1, for step j at
-// tap t: steps j-1 .. j-(S-2), 9 at a tap-0 step, else 2.  At tap 8 the next slice's halo (issued first in this slice's
-// tap-0 step, 2 + 7*2 younger instructions) must have landed as well.
-template <int S>
-constexpr int younger_dmas(int t) {
-    int n = 0;
-    for (int i = 1; i <= S - 2; ++i) n += ((t - i) % 9 + 9) % 9 == 0 ? 9 : 2;
-    if (t == 8 && n > 16) n = 16;
-    return n;
-}
-template <int S>
+// DMA instructions a wave issues after weight tile j+1 (the last thing step j-2 issued) up to step j-1, for step j at
+// tap t: step j-1 only - 9 when that was a tap-0 step (7 halo pieces + 2 weight pieces), else 2
 __device__ __forceinline__ void wait_step(int t) {
-    switch (t) {                                                  // t is a compile-time constant after unrolling
-        case 0: wait_vm<younger_dmas<S>(0)>(); break;
-        case 1: wait_vm<younger_dmas<S>(1)>(); break;
-        case 2: wait_vm<younger_dmas<S>(2)>(); break;
-        case 3: wait_vm<younger_dmas<S>(3)>(); break;
-        case 4: wait_vm<younger_dmas<S>(4)>(); break;
-        case 5: wait_vm<younger_dmas<S>(5)>(); break;
-        case 6: wait_vm<younger_dmas<S>(6)>(); break;
-        case 7: wait_vm<younger_dmas<S>(7)>(); break;
-        default: wait_vm<younger_dmas<S>(8)>(); break;
-    }
+    if (t == 1) wait_vm<9>();                                     // t is a compile-time constant after unrolling
+    else wait_vm<2>();
 }
 
 // bank-conflict swizzle of a halo slot's 16-byte chunks: ds_read_b128 serves lanes in groups of 16 over 64 banks, a
@@ -95,19 +81,22 @@ __device__ __forceinline__ int halo_swz(int hy, int hx) {
 
 struct Frags { h8_t w[4], x0[4], x1[4]; };
 
-template <int TW, int S>
+__device__ __forceinline__ h8_t lds_read(unsigned byte_addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) h8_t*>((uintptr_t)byte_addr);
+}
+
+template <int TW>
 __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
     constexpr int NSB = 16 / TW;                 // sub-blocks of 8 x TW pixels per tile
     constexpr int HWD = TW + 2;                  // halo row width (even)
     constexpr int HS = 10 * HWD;                 // halo slots per sub-block
     constexpr int NSLOT = NSB * HS;              // 180 (TW = 16) / 200 (TW = 8)
     constexpr int NPIECE = (NSLOT + 7) / 8;      // DMA pieces (8 slots x 128 B) per halo buffer
+    constexpr int NPAR = TW == 16 ? 1 : 2;       // halo-row parities the swizzle distinguishes
+    constexpr int MT1 = (32 / TW) * HWD * 128;   // byte distance of the wave's second 32-pixel fragment in the halo
     static_assert(NPIECE <= kAPiecesMax && NPIECE <= 28, "halo does not fit");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* lds = reinterpret_cast<half_t*>(smem);
-    half_t* dummy = lds + 2 * kAHalves;
-    half_t* bring = dummy + kDummy;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -127,76 +116,94 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
     const int n0 = bn * BN;
     const int cb = sp * p.cps, ce = min(p.nc, cb + p.cps);
     const int ns = (ce - cb) * 9;
-    const long long Kw = 9ll * p.Cin;
 
-    // ---- halo DMA sources: 7 pieces per wave; slot = piece * 8 + lane / 8, LDS chunk lane % 8 <- global chunk ^ swz(slot)
-    int aoff[7];                             // element offset of the lane's 16 bytes within slice 0, -1 = zero page
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- weight DMA: piece = 8 rows x 128 B, 2 pieces per wave; LDS chunk lane % 8 <- global chunk ^ ((row >> 1) & 7)
+    // (a 128-byte row covers half the banks, the half being the row parity: conflict-free 16-lane read groups)
+    unsigned wvoff[2];
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+        const int row = (pc * 4 + wave) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        wvoff[pc] = ((unsigned)(n0 + row) * 9u * (unsigned)p.Cin + chunk * 8) * 2u;
+    }
+    auto issue_b = [&](unsigned soff, int stage) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dma16(wr, wvoff[pc], soff, kRingOff + stage * kBStageBytes + (pc * 4 + wave) * 1024);
+    };
+    auto tile_soff = [&](int c, int t) { return ((unsigned)t * (unsigned)p.Cin + (unsigned)c * BK) * 2u; };
+
+    // the weight tiles of steps 0..2 go out first: their latency overlaps the halo index arithmetic below
+    issue_b(tile_soff(cb, 0), 0);
+    issue_b(tile_soff(cb, 1), 1);            // ns >= 9
+    issue_b(tile_soff(cb, 2), 2);
+
+    // ---- sub-block origins (wave-uniform: at most two per tile, so the runtime divisions run once, not per lane)
+    int ob[NSB], oy[NSB], ox[NSB];
+#pragma unroll
+    for (int sb = 0; sb < NSB; ++sb) {
+        const int g = bm * NSB + sb;
+        const int b = g / p.bpi, r2 = g - b * p.bpi, byy = r2 / p.bpr;
+        ob[sb] = g < p.nblk ? b : -1;            // -1: the tile's last sub-block does not exist
+        oy[sb] = byy * 8; ox[sb] = (r2 - byy * p.bpr) * TW;
+    }
+    // ---- halo DMA: 7 pieces per wave; slot = piece * 8 + lane / 8, LDS chunk lane % 8 <- global chunk ^ swz(slot);
+    // slots outside the image (zero padding), beyond the halo or of a missing sub-block read out of bounds -> zeros
+    unsigned aoff[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        const int piece = i * 4 + wave;
-        const int slot = piece * 8 + (lane >> 3);
-        int px = -1, sw = 0;
+        const int slot = (i * 4 + wave) * 8 + (lane >> 3);
+        unsigned off = kOob;
         if (slot < NSLOT) {
             const int sb = slot / HS, rem = slot % HS;
             const int hy = rem / HWD, hx = rem % HWD;
-            sw = halo_swz<TW>(hy, hx);
-            const int g = bm * NSB + sb;
-            if (g < p.nblk) {
-                const int b = g / p.bpi, r2 = g % p.bpi;
-                const int y = (r2 / p.bpr) * 8 - 1 + hy, x = (r2 % p.bpr) * TW - 1 + hx;
-                if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-                    px = p.up ? (b * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1) : (b * p.H + y) * p.W + x;
+            const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
+            const int y = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) - 1 + hy;
+            const int x = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) - 1 + hx;
+            if (b >= 0 && y >= 0 && y < p.H && x >= 0 && x < p.W) {
+                const int px = p.up ? (b * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1) : (b * p.H + y) * p.W + x;
+                off = ((unsigned)px * (unsigned)p.ldx + (((lane & 7) ^ halo_swz<TW>(hy, hx)) << 3)) * 2u;
             }
         }
-        aoff[i] = px >= 0 ? px * (int)p.ldx + ((lane & 7) ^ sw) * 8 : -1;
+        aoff[i] = off;
     }
-
     auto issue_a = [&](int i, int c, int ab) {
         const int piece = i * 4 + wave;
-        half_t* dst = piece < NPIECE ? lds + ab * kAHalves + piece * 512 : dummy;
-        const half_t* src = aoff[i] >= 0 ? p.x + aoff[i] + c * BK : g_zero_page;
-        dma16(src, dst);
+        const unsigned dst = piece < NPIECE ? kAOff + ab * kABytes + piece * 1024 : kPadOff;
+        dma16(xr, aoff[i], (unsigned)c * (BK * 2), dst);
     };
-    // weight tile: row n of the tile at 128 B pitch, chunk ^ ((row >> 1) & 7): conflict-free for 16-lane read groups
-    auto issue_b = [&](int c, int t, int stg) {
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc) {
-            const int piece = pc * 4 + wave;
-            const int row = piece * 8 + (lane >> 3);
-            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            dma16(p.w + (long long)(n0 + row) * Kw + (long long)t * p.Cin + c * BK + chunk * 8,
-                  bring + stg * kBStage + piece * 512);
-        }
-    };
-
-    // ---- MFMA operand rows: fragment mt of this wave covers pixels wm*64 + mt*32 + r of the tile; the two fragments
-    // share the halo column and the halo row parity, hence the swizzle
-    int s0[2];
-    int hy0, hx0;
+    // ---- MFMA operand addresses (bytes).  Fragment 0 of this wave covers pixels wm*64 + r, fragment 1 the 32 pixels
+    // after them: the same halo column, 2 (TW = 16) or 4 (TW = 8) halo rows below -> a constant byte distance.
+    // xaddr[par][dx][ks]: top-left tap (dy = dx = -1) slot + dx, chunk (2 ks + hh) ^ swizzle; a tap adds dy * pitch.
+    unsigned xaddr[NPAR][3][4], waddr[4];
     {
         const int m = wm * 64 + r;
         const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
-        hy0 = py + 1; hx0 = pxl + 1;
-        s0[0] = sb * HS + hy0 * HWD + hx0;
-        const int m1 = m + 32;
-        s0[1] = (m1 / (8 * TW)) * HS + ((m1 % (8 * TW)) / TW + 1) * HWD + hx0;
+        const int slot00 = sb * HS + py * HWD + pxl;             // halo slot of tap (-1, -1)
+#pragma unroll
+        for (int par = 0; par < NPAR; ++par)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int sw = halo_swz<TW>(py + par, pxl + dx);   // par = parity offset of the tap row (dy index & 1)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xaddr[par][dx][ks] = (unsigned)((slot00 + dx) * 128 + (((2 * ks + hh) ^ sw) << 4));
+            }
+        const int wrow = wn * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) waddr[ks] = (unsigned)(wrow * 128 + (((2 * ks + hh) ^ ((wrow >> 1) & 7)) << 4));
     }
-    const int wrow = wn * 32 + r;
-    const int wsw = (wrow >> 1) & 7;
-
-    auto load_frags = [&](Frags& f, const half_t* a, const half_t* b, int t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        const int off = dy * HWD + dx;
-        const int xsw = halo_swz<TW>(hy0 + dy, hx0 + dx);
-        const half_t* a0 = a + (s0[0] + off) * BK;
-        const half_t* a1 = a + (s0[1] + off) * BK;
-        const half_t* bw = b + wrow * BK;
+    // fragments of step (halo buffer ab, tap t, ring stage t % 3)
+    auto load_frags = [&](Frags& f, int ab, int t) {
+        const int dy = t / 3, dx = t % 3;
+        const unsigned abase = kAOff + ab * kABytes + dy * HWD * 128;
+        const unsigned bbase = kRingOff + (t % 3) * kBStageBytes;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int kc = 2 * ks + hh;
-            f.w[ks] = *reinterpret_cast<const h8_t*>(bw + ((kc ^ wsw) << 3));
-            f.x0[ks] = *reinterpret_cast<const h8_t*>(a0 + ((kc ^ xsw) << 3));
-            f.x1[ks] = *reinterpret_cast<const h8_t*>(a1 + ((kc ^ xsw) << 3));
+            f.w[ks] = lds_read(waddr[ks] + bbase);
+            f.x0[ks] = lds_read(xaddr[NPAR == 1 ? 0 : (dy & 1)][dx][ks] + abase);
+            f.x1[ks] = lds_read(xaddr[NPAR == 1 ? 0 : (dy & 1)][dx][ks] + abase + MT1);
         }
     };
 
@@ -204,63 +211,66 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 
-    // Every step issues a number of DMA instructions per wave that depends on its tap only (tap 0: the next slice's 7
-    // halo pieces + 2 weight pieces, other taps: 2 weight pieces; a 16-byte zero-page read into the landing pad where
-    // there is nothing to fetch), so "tile j+1 has landed" is a compile-time vmcnt per tap (younger_dmas).
-    auto dummy_dma = [&]() { dma16(g_zero_page, dummy); };
-
-    // ---- prologue: halo of the first slice and the weight tiles of steps 0..S-1 in flight; step 0's fragments in registers
+    // ---- prologue: halo of the first slice (issued after the three weight tiles: everything must land); step 0's
+    // fragments in registers
 #pragma unroll
     for (int i = 0; i < 7; ++i) issue_a(i, cb, 0);
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        if (k < ns) issue_b(cb + k / 9, k % 9, k);
-        else { dummy_dma(); dummy_dma(); }
-    }
-    wait_vm<2 * (S - 1)>();
+    wait_vm<0>();
     __builtin_amdgcn_s_barrier();
-    Frags cur, nxt;
-    load_frags(cur, lds, bring, 0);
+    Frags f[2];
+    load_frags(f[0], 0, 0);
     if (p.stamps) { st1 = __builtin_amdgcn_s_memrealtime(); sc1 = __builtin_amdgcn_s_memtime(); }
 
     // ---- main loop.  Step j = (slice c, tap t).  The barrier of step j publishes weight tile j+1 (and, at t = 8, the
-    // next slice's halo), proves every wave holds tile j in registers (so its ring stage is refilled with tile j+S), and
-    // the fragments of step j+1 are read while step j's MFMAs run.
-    int j = 0, stg = 0;                      // stg = j % S = ring stage of tile j
-    for (int c = cb; c < ce; ++c) {
-        const int ab = (c - cb) & 1;
-        const bool has_next = c + 1 < ce;
-        const half_t* a = lds + ab * kAHalves;
+    // next slice's halo), proves every wave holds tile j in registers (so its ring stage is refilled with tile j+3), and
+    // the fragments of step j+1 are read while step j's MFMAs run.  A step has no branch: past the last tile / slice the
+    // DMAs re-fetch a valid tile into a stage nobody reads again, and the last fragment read is discarded.
+    // Every step issues 2 weight pieces (+ the next slice's 7 halo pieces at tap 0) per wave: compile-time vmcnt.
+    // The slice body is instantiated for both parities of the slice index: 9 steps flip which register set is "current".
+    auto slice = [&](auto parity, int c) {
+        constexpr int P = decltype(parity)::value;               // halo buffer of this slice; f[P] holds tap 0's fragments
+        const int jb = (c - cb) * 9;
+        const int cn = c + 1 < ce ? c + 1 : c;
 #pragma unroll
-        for (int t = 0; t < 9; ++t, ++j) {
-            // tile j+1 was issued last in step j+1-S; while it still is a prologue tile (j < S-1) at least the 2(S-2-j)
-            // later prologue pieces + the steps so far are younger: 2S-4 is a safe (early) bound there
-            if (j >= S - 1) wait_step<S>(t);
-            else wait_vm<2 * S - 4>();
+        for (int t = 0; t < 9; ++t) {
+            Frags& cur = f[(P + t) & 1];
+            Frags& nxt = f[(P + t + 1) & 1];
+            wait_step(t);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // step j's fragments are in registers
             __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);                       // keep step j+1's MFMAs out of step j (they would wait on their reads)
             if (t == 0) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    if (has_next) issue_a(i, c + 1, ab ^ 1);
-                    else dummy_dma();
-                }
+                for (int i = 0; i < 7; ++i) issue_a(i, cn, P ^ 1);
             }
-            if (j + S < ns) issue_b(c + (t + S) / 9, (t + S) % 9, stg);
-            else { dummy_dma(); dummy_dma(); }
-            if (j + 1 < ns) {
-                const int s1 = stg == S - 1 ? 0 : stg + 1;
-                if (t < 8) load_frags(nxt, a, bring + s1 * kBStage, t + 1);
-                else load_frags(nxt, lds + (ab ^ 1) * kAHalves, bring + s1 * kBStage, 0);
+            {
+                const bool more = jb + t + 3 < ns;
+                const int c3 = t + 3 >= 9 ? c + 1 : c, t3 = (t + 3) % 9;
+                issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % 3);
             }
+            if (t < 8) load_frags(nxt, P, t + 1);
+            else load_frags(nxt, P ^ 1, 0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 acc[0] = mfma_32x32x16(cur.w[ks], cur.x0[ks], acc[0]);
                 acc[1] = mfma_32x32x16(cur.w[ks], cur.x1[ks], acc[1]);
             }
-            cur = nxt;
-            stg = stg == S - 1 ? 0 : stg + 1;
+            // issue order within the step (the loop is instruction-issue bound: one wave per SIMD, and a 32-cycle MFMA
+            // hides ~24 cycles of other issue): the next fragments' 12 LDS reads ride in the first four MFMA gaps so
+            // the last four MFMAs cover their latency; the DMAs (1 KiB each, ~60 cycles of issue) one per gap
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                 // VMEM read (first DMA piece)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                if (g < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);               // MFMA
+                if (g < (t == 0 ? 8 : 1)) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    for (int c = cb; c < ce; ++c) {
+        if ((c - cb) & 1) slice(std::integral_constant<int, 1>{}, c);
+        else slice(std::integral_constant<int, 0>{}, c);
     }
     if (p.stamps) { st2 = __builtin_amdgcn_s_memrealtime(); sc2 = __builtin_amdgcn_s_memtime(); }
     __syncthreads();
@@ -278,11 +288,11 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
         const int idx = threadIdx.x + cidx * T, m = idx >> 3, ch = idx & 7;
-        const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
-        const int g = bm * NSB + sb;
-        if (g >= p.nblk) continue;
-        const int b = g / p.bpi, r2 = g % p.bpi;
-        const long long gp = ((long long)b * p.H + (r2 / p.bpr) * 8 + py) * p.W + (r2 % p.bpr) * TW + pxl;
+        const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;      // sb = cidx / 2 for TW = 8: uniform
+        const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
+        if (b < 0) continue;
+        const long long gp = ((long long)b * p.H + (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py) * p.W +
+                             (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
         const float* sp_ = stage + m * kEpiStride + ch * 8;
         if (p.splits > 1) {
             float* dst = p.ws + ((long long)sp * p.npix + gp) * p.Cout + n0 + ch * 8;
@@ -333,7 +343,6 @@ __global__ __launch_bounds__(256) void conv3x3_reduce(ConvParams p) {
 }
 
 long long* g_conv_stamps = nullptr;
-int g_conv_ring = 0;
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -375,11 +384,10 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
-extern "C" void dsc_debug_set_conv_ring(int stages) { g_conv_ring = stages; }
-
 extern "C" int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
     ConvParams p{};
-    if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W * (long long)(Cin > Cout ? Cin : Cout) >= (1ll << 31)) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W * (long long)(Cin > Cout ? Cin : Cout) >= (1ll << 30) ||
+        9ll * Cin * Cout >= (1ll << 30)) return 0;
     return plan(B, H, W, Cin, Cout, 0, &p) ? 1 : 0;
 }
 
@@ -398,7 +406,8 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     if (ldx < Cin || ldo < Cout || (residual && ldr < Cout)) return DSC_ERR_BAD_ARG;
     if (ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(w) || !al16(out) || (bias && !al16(bias)) || (residual && !al16(residual))) return DSC_ERR_UNSUPPORTED;
-    if ((long long)B * H * W * (ldx > ldo ? ldx : ldo) >= (1ll << 31)) return DSC_ERR_UNSUPPORTED;
+    // 32-bit byte offsets in the buffer-addressed DMAs (and kOob must lie beyond every extent)
+    if ((long long)B * H * W * (ldx > ldo ? ldx : ldo) >= (1ll << 30) || 9ll * Cin * Cout >= (1ll << 30)) return DSC_ERR_UNSUPPORTED;
     ConvParams p{};
     const int tw = plan(B, H, W, Cin, Cout, splits, &p);
     if (!tw) return DSC_ERR_UNSUPPORTED;
@@ -408,6 +417,11 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.stamps = g_conv_stamps;
     p.up = upsample2x ? 1 : 0;
+    {
+        const long long in_pix = upsample2x ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
+        p.x_bytes = (unsigned)(((in_pix - 1) * ldx + Cin) * 2);
+        p.w_bytes = (unsigned)(9ll * Cin * Cout * 2);
+    }
     if (p.splits > 1) {
         const size_t need = (size_t)p.splits * p.npix * Cout * sizeof(float);
         if (!workspace || workspace_bytes < need || !al16(workspace)) return DSC_ERR_WORKSPACE;
@@ -415,23 +429,14 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(&conv3x3_kernel<16, 3>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 3>),
-                             reinterpret_cast<const void*>(&conv3x3_kernel<16, 6>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 6>),
-                             reinterpret_cast<const void*>(&conv3x3_kernel<16, 10>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 10>)};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int total = p.mt * p.nt * p.splits;
     const dim3 grid(((total + 7) / 8) * 8), block(T);
-    // ring depth: 3 stages (75 KiB, two workgroups per CU).  Deeper rings (6 / 10 stages, one workgroup per CU) were
-    // measured and do not shorten a step: the loop is bound by instruction issue, not by L2->LDS latency
-    int ring = g_conv_ring;
-    if (ring != 3 && ring != 6 && ring != 10) ring = 3;
-    const size_t lds = (size_t)lds_halves(ring) * sizeof(half_t);
-#define DSC_CONV_LAUNCH(TW_, S_) hipLaunchKernelGGL((conv3x3_kernel<TW_, S_>), grid, block, lds, st, p)
-    if (tw == 16) { if (ring == 3) DSC_CONV_LAUNCH(16, 3); else if (ring == 6) DSC_CONV_LAUNCH(16, 6); else DSC_CONV_LAUNCH(16, 10); }
-    else { if (ring == 3) DSC_CONV_LAUNCH(8, 3); else if (ring == 6) DSC_CONV_LAUNCH(8, 6); else DSC_CONV_LAUNCH(8, 10); }
-#undef DSC_CONV_LAUNCH
+    if (tw == 16) hipLaunchKernelGGL((conv3x3_kernel<16>), grid, block, (size_t)kLdsBytes, st, p);
+    else hipLaunchKernelGGL((conv3x3_kernel<8>), grid, block, (size_t)kLdsBytes, st, p);
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     if (p.splits > 1) {
         const long long n = p.npix * (Cout / 8);
