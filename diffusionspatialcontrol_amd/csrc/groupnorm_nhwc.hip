@@ -6,7 +6,7 @@
 // workgroup), so every load/store is a coalesced 16-byte access and the per-channel constants stay in registers.
 //   launch 1 gn_nhwc_stats    : per-thread channel sums -> LDS [k][C] -> per-channel -> per-group (sum, sumsq) in
 //                               fp64 -> partials[b][chunk][g]
-//   launch 2 gn_nhwc_finalize : one workgroup per image adds the chunk partials (fixed order) -> (mean, rstd)[b][g].
+//   launch 2 gn_nhwc_finalize : one wave per (image, group) adds the chunk partials (fixed order) -> (mean, rstd)[b][g].
 //                               Without it every apply workgroup re-read all nchunk x G partials (64 KB, more than
 //                               its own 40 KB of activations)
 //   launch 3 gn_nhwc_apply    : folds mean/rstd/gamma/beta(/add) into one scale+shift per channel, streams its rows:
@@ -63,24 +63,17 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
     }
 }
 
-__global__ __launch_bounds__(256) void gn_nhwc_finalize(GnN p) {
-    __shared__ double red[256 * 2];
-    const int b = blockIdx.x;
-    const int np = 256 / p.G;                                // G <= 64
-    const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+// one wave per (image, group): lane i adds chunk partials i, i+64, ... (fixed order), then a fixed-order butterfly
+__global__ __launch_bounds__(64) void gn_nhwc_finalize(GnN p) {
+    const int b = blockIdx.x / p.G, g = blockIdx.x % p.G;
+    const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
     double a1 = 0.0, a2 = 0.0;
-    if (part < np) {
-        const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
-        for (int i = part; i < p.nchunk; i += np) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
-    }
-    red[2 * threadIdx.x] = a1; red[2 * threadIdx.x + 1] = a2;
-    __syncthreads();
-    if (threadIdx.x < p.G) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int q = 0; q < np; ++q) { t1 += red[2 * (q * p.G + g)]; t2 += red[2 * (q * p.G + g) + 1]; }
+    for (int i = threadIdx.x; i < p.nchunk; i += 64) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+    a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2);
+    if (threadIdx.x == 0) {
         const double n = (double)p.HW * p.cpg;
-        const double m = t1 / n;
-        double var = t2 / n - m * m;
+        const double m = a1 / n;
+        double var = a2 / n - m * m;
         var = var > 0.0 ? var : 0.0;
         p.stats[((long long)b * p.G + g) * 2] = (float)m;
         p.stats[((long long)b * p.G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
@@ -271,7 +264,7 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     }
     const dim3 grid(B * p.nchunk), block(p.cv * p.k);
     hipLaunchKernelGGL(gn_nhwc_stats, grid, block, (size_t)2 * p.k * C * sizeof(float), st, p);
-    hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
     hipLaunchKernelGGL(gn_nhwc_apply, grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
