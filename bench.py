@@ -20,6 +20,7 @@ Extra objects on the JSON line:
                  per UNet row (2*(2*L*C + 2*S*C) + 4*L*S at L=4096, C=320, S=77) x Bc rows.
   roofline_self_attn - the flash self-attention kernel at the same level against the 2.5 PFLOP/s dense fp16 MFMA peak
                  (4*L^2*C FLOPs per row).
+  roofline_conv3x3   - the 3x3 convolution kernel (64x64, 320->320, the most frequent one) against the same peak
   cpu_baseline - the oracle (oracle/unet_ref.py, torch fp32, op-for-op unfused like the reference) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -170,6 +171,22 @@ def roofline_self_attn(dev, n_img):
             "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2)}
 
 
+def roofline_conv3x3(dev, n_img):
+    """The 3x3 convolution kernel at the 64x64 level (320 -> 320 channels), the most frequent convolution of a step: MFMA-bound."""
+    from diffusionspatialcontrol_amd import ops
+    Bc, C, hw = 2 * n_img, 320, 64
+    g = torch.Generator().manual_seed(6)
+    cl = torch.channels_last
+    x = torch.randn(Bc, C, hw, hw, generator=g).half().to(dev).contiguous(memory_format=cl)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3.0 * C ** 0.5)).half().to(dev).contiguous(memory_format=cl)
+    us = graph_launch_time_us(lambda: ops.conv3x3(x, w, None), launches=20, replays=5)
+    flops = 2.0 * Bc * hw * hw * C * C * 9
+    tf = flops / (us * 1e-6) / 1e12
+    return {"kernel": "conv3x3_kernel<16> (3x3 convolution, 64x64, 320->320, Bc=%d)" % Bc, "bound": "mfma",
+            "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2)}
+
+
 def host_cores():
     """cores this process may actually use (the GPU box exposes 256 logical CPUs but grants a share of them)"""
     try:
@@ -298,6 +315,7 @@ def main():
         }
         res["roofline"] = roofline_region_xattn(dev, n_img)
         res["roofline_self_attn"] = roofline_self_attn(dev, n_img)
+        res["roofline_conv3x3"] = roofline_conv3x3(dev, n_img)
         if world == 1 and not a.no_cpu_baseline:
             from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
             rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)

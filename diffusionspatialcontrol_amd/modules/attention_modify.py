@@ -167,6 +167,7 @@ class _RegionProcessor:
     """Shared body of AttnProcessor / AttnProcessor2_0 (reference :106-207 and :414-503)."""
 
     honours_attn_scale = False
+    is_ip_adapter = False
 
     def __init__(self, n_std_groups: int = 1, ref_fp16_rounding: bool = False):
         # 1 = the reference: ONE std over the whole call (all rows, all heads).  The pipeline sets B when it
@@ -182,6 +183,9 @@ class _RegionProcessor:
                  region_prompt=None, ip_adapter_masks=None) -> torch.Tensor:
         residual = hidden_states
         img_sequence_length = hidden_states.shape[1]              # :427 - dim 1 also for 4-D input
+        ip_hidden_states = None
+        if self.is_ip_adapter and encoder_hidden_states is not None:
+            encoder_hidden_states, ip_hidden_states = self._split_ip(encoder_hidden_states)
         if attn.spatial_norm is not None:
             hidden_states = attn.spatial_norm(hidden_states, temb)
         input_ndim = hidden_states.ndim
@@ -239,6 +243,8 @@ class _RegionProcessor:
         else:
             out = ops.self_attention(q4, k4, v4, scale=sc)                  # [B, L, H, d]
         hidden_states = out.reshape(B, L, C)
+        if self.is_ip_adapter:
+            hidden_states = self._ip_branch(attn, q4, hidden_states, ip_hidden_states, ip_adapter_masks, sc)
         to_out = attn.to_out[0]
         hidden_states = ops.linear(hidden_states, to_out.weight, to_out.bias) if type(to_out) is nn.Linear \
             else to_out(hidden_states)
@@ -269,3 +275,106 @@ class AttnProcessor(_RegionProcessor, nn.Module):
         return _RegionProcessor.__call__(self, *a, **k)
 
     __call__ = _RegionProcessor.__call__
+
+
+# ----------------------------------------------------------------------------- IP-Adapter
+class IPAdapterMaskProcessor:
+    """`downsample` of diffusers 0.27.2 `IPAdapterMaskProcessor` (imported at reference attention_modify.py:25, called at
+    :373-376 and :672-675).  diffusers is not part of the reference tree nor of this image: restated from the published
+    algorithm, PARITY UNPINNED (oracle/region_attention.py `ip_mask_downsample` is the same restatement)."""
+
+    @staticmethod
+    def downsample(mask: torch.Tensor, batch_size: int, num_queries: int, value_embed_dim: int):
+        o_h, o_w = mask.shape[1], mask.shape[2]
+        ratio = o_w / o_h
+        mask_h = int(math.sqrt(num_queries / ratio))
+        mask_h = int(mask_h) + int((num_queries % int(mask_h)) != 0)
+        mask_w = num_queries // mask_h
+        m = F.interpolate(mask.unsqueeze(0), size=(mask_h, mask_w), mode="bicubic").squeeze(0)
+        if m.shape[0] < batch_size:
+            m = m.repeat(batch_size, 1, 1)
+        m = m.view(m.shape[0], -1)
+        area = mask_h * mask_w
+        if area < num_queries:
+            m = F.pad(m, (0, num_queries - m.shape[1]), value=0.0)
+        if area > num_queries:
+            m = m[:, :num_queries]
+        return m.view(m.shape[0], m.shape[1], 1).repeat(1, 1, value_embed_dim)
+
+
+class _IPAdapterProcessor(_RegionProcessor, nn.Module):
+    """Shared body of the two IP-Adapter processors (reference :208-404 and :506-700): the text branch is the region
+    cross-attention of `_RegionProcessor`; every adapter adds `scale_i * softmax(q k_ip^T) v_ip` (optionally times a
+    down-sampled mask) of the SAME queries before the output projection.  Constructor arguments, attribute names and
+    the `to_k_ip` / `to_v_ip` ModuleLists (hence the state-dict keys `_load_ip_adapter_weights` fills) are the
+    reference's.  The image-token attention (4 / 16 tokens per adapter) runs on the generic HIP kernel without a table."""
+
+    is_ip_adapter = True
+
+    def __init__(self, hidden_size, cross_attention_dim=None, num_tokens=(4,), scale=1.0, n_std_groups: int = 1,
+                 ref_fp16_rounding: bool = False):
+        nn.Module.__init__(self)
+        _RegionProcessor.__init__(self, n_std_groups, ref_fp16_rounding)
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        if not isinstance(num_tokens, (tuple, list)):
+            num_tokens = [num_tokens]
+        self.num_tokens = num_tokens
+        if not isinstance(scale, list):
+            scale = [scale] * len(num_tokens)
+        if len(scale) != len(num_tokens):
+            raise ValueError("`scale` should be a list of integers with the same length as `num_tokens`.")
+        self.scale = scale
+        self.to_k_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in num_tokens])
+        self.to_v_ip = nn.ModuleList([nn.Linear(cross_attention_dim, hidden_size, bias=False) for _ in num_tokens])
+
+    def _split_ip(self, encoder_hidden_states):
+        if isinstance(encoder_hidden_states, tuple):
+            return encoder_hidden_states
+        # deprecated single-tensor form (:568-577): the last num_tokens[0] rows are the (single) adapter's image tokens
+        end_pos = encoder_hidden_states.shape[1] - self.num_tokens[0]
+        return encoder_hidden_states[:, :end_pos, :], [encoder_hidden_states[:, end_pos:, :]]
+
+    def _ip_branch(self, attn, q4, hidden_states, ip_hidden_states, ip_adapter_masks, sc):
+        if ip_adapter_masks is not None:
+            if not isinstance(ip_adapter_masks, torch.Tensor) or ip_adapter_masks.ndim != 4:
+                raise ValueError(" ip_adapter_mask should be a tensor with shape [num_ip_adapter, 1, height, width]."
+                                 " Please use `IPAdapterMaskProcessor` to preprocess your mask")
+            if len(ip_adapter_masks) != len(self.scale):
+                raise ValueError(f"Number of ip_adapter_masks ({len(ip_adapter_masks)}) must match number of IP-Adapters "
+                                 f"({len(self.scale)})")
+        else:
+            ip_adapter_masks = [None] * len(self.scale)
+        if ip_hidden_states is None:                 # self-attention call: the reference would fail on an unbound name
+            return hidden_states
+        B, L, H, d = q4.shape
+        for cur, scale, to_k_ip, to_v_ip, mask in zip(ip_hidden_states, self.scale, self.to_k_ip, self.to_v_ip, ip_adapter_masks):
+            T = cur.shape[1]
+            k4 = to_k_ip(cur).view(B, T, H, d)
+            v4 = to_v_ip(cur).view(B, T, H, d)
+            if T <= 96:
+                o = ops.region_xattn(q4, k4, v4, None, layout="blhd", scale=sc, ref_fp16_rounding=False)
+            else:                                     # long image-token sequences (257-token variants): library attention
+                o = F.scaled_dot_product_attention(q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2),
+                                                   scale=sc).transpose(1, 2)
+            o = o.reshape(B, L, H * d)
+            if mask is not None:
+                md = IPAdapterMaskProcessor.downsample(mask, B, o.shape[1], o.shape[2])
+                o = o * md.to(dtype=o.dtype, device=o.device)
+            hidden_states = hidden_states + scale * o
+        return hidden_states
+
+    def forward(self, *a, **k):
+        return _RegionProcessor.__call__(self, *a, **k)
+
+    __call__ = _RegionProcessor.__call__
+
+
+class IPAdapterAttnProcessor2_0(_IPAdapterProcessor):
+    r"""Counterpart of reference `IPAdapterAttnProcessor2_0` (:506-700): scale 1/sqrt(head_dim) on every branch."""
+    honours_attn_scale = False
+
+
+class IPAdapterAttnProcessor(_IPAdapterProcessor):
+    r"""Counterpart of reference `IPAdapterAttnProcessor` (:208-404): scores use `attn.scale` (:57-63)."""
+    honours_attn_scale = True

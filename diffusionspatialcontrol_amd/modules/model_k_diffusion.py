@@ -74,6 +74,7 @@ class StableDiffusionPipeline:
         self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
         self._do_classifier_free_guidance = True
         self._graphs = {}
+        self._added_cond_kwargs = None
         self.setup_unet(self.unet)
 
     # ------------------------------------------------------------------ reference surface
@@ -177,6 +178,60 @@ class StableDiffusionPipeline:
             return image
         return image[0]
 
+    # ---- IP-Adapter surface (reference ip_adapter.py:48-292, state-dict form)
+    def load_ip_adapter(self, pretrained_model_name_or_path_or_dict, subfolder=None, weight_name=None,
+                        image_encoder_folder=None, **kwargs):
+        """ip_adapter.py:48-239 restricted to what works offline: `pretrained_model_name_or_path_or_dict` must be a
+        state dict {"image_proj": ..., "ip_adapter": ...} or a list of them; the CLIP image encoder is not loaded
+        (pass `ip_adapter_image_embeds` to txt2img, as the reference's own warning at :219-222 suggests)."""
+        sds = pretrained_model_name_or_path_or_dict
+        if not isinstance(sds, list):
+            sds = [sds]
+        for sd in sds:
+            if not isinstance(sd, dict) or sorted(sd.keys()) != ["image_proj", "ip_adapter"]:
+                raise ValueError("Required keys are (`image_proj` and `ip_adapter`) missing from the state dict.")   # :191-192
+        self._graphs = {}
+        return self.unet._load_ip_adapter_weights(sds, low_cpu_mem_usage=False)
+
+    def set_ip_adapter_scale(self, scale):
+        """ip_adapter.py:242-264"""
+        from .attention_modify import IPAdapterAttnProcessor, IPAdapterAttnProcessor2_0
+        for proc in self.unet.attn_processors.values():
+            if isinstance(proc, (IPAdapterAttnProcessor, IPAdapterAttnProcessor2_0)):
+                sc = scale if isinstance(scale, list) else [scale] * len(proc.scale)
+                if len(proc.scale) != len(sc):
+                    raise ValueError(f"`scale` should be a list of same length as the number if ip-adapters "
+                                     f"Expected {len(proc.scale)} but got {len(sc)}.")
+                proc.scale = sc
+        self._graphs = {}                            # the scales are baked into a captured step
+
+    def unload_ip_adapter(self):
+        """ip_adapter.py:266-292: drops the image projection and restores plain processors.  (The reference's
+        has-SDPA test is inverted and installs `AttnProcessor`; both classes compute the same function)"""
+        from .attention_modify import AttnProcessor
+        self.unet.encoder_hid_proj = None
+        self.unet.config["encoder_hid_dim_type"] = None
+        self.unet.set_attn_processor(AttnProcessor())
+        self._graphs = {}
+
+    def prepare_ip_adapter_image_embeds(self, ip_adapter_image, ip_adapter_image_embeds, device, num_images_per_prompt,
+                                        do_classifier_free_guidance):
+        """Reference :173-222, pre-computed-embeddings branch (:203-221): each list entry holds [negative; positive]
+        along dim 0 when CFG is on; both halves are repeated per image and re-concatenated."""
+        if ip_adapter_image_embeds is None:
+            raise NotImplementedError("encoding ip_adapter_image needs the CLIP image encoder (a 'next' row): pass "
+                                      "ip_adapter_image_embeds")
+        out = []
+        for e in ip_adapter_image_embeds:
+            ones = [1] * (e.dim() - 1)
+            if do_classifier_free_guidance:
+                neg, pos = e.chunk(2)
+                e = torch.cat([neg.repeat(num_images_per_prompt, *ones), pos.repeat(num_images_per_prompt, *ones)])
+            else:
+                e = e.repeat(num_images_per_prompt, *ones)
+            out.append(e)
+        return out
+
     # ------------------------------------------------------------------ txt2img
     @torch.no_grad()
     def txt2img(self, prompt: Union[str, List[str], None] = None, height: int = 512, width: int = 512,
@@ -191,10 +246,11 @@ class StableDiffusionPipeline:
                 # build-specific inputs (the prompt encoders are a "next" row):
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                 text_input_ids=None, fused: Optional[bool] = None, **unsupported):
-        if upscale or ip_adapter_image is not None or ip_adapter_image_embeds is not None or control_img is not None \
+        if upscale or ip_adapter_image is not None or control_img is not None \
                 or image_t2i_adapter is not None or self.controlnet is not None or latent_processing:
-            raise NotImplementedError("hires upscale / IP-Adapter / ControlNet / T2I-Adapter / latent previews are "
-                                      "outside the denoising hot path built here (SURVEY.md 8f)")
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images (CLIP image encoder) / ControlNet / "
+                                      "T2I-Adapter / latent previews are outside the denoising hot path built here "
+                                      "(SURVEY.md 8f); pass ip_adapter_image_embeds for IP-Adapter")
         if prompt_embeds is None:
             raise NotImplementedError("prompt encoding (CLIP + A1111 chunking, encoder_prompt_modify.py) is a 'next' "
                                       "row: pass prompt_embeds / negative_prompt_embeds / text_input_ids")
@@ -219,6 +275,11 @@ class StableDiffusionPipeline:
         region_state = encode_region_map(self, region_map_state, width=width, height=height,
                                          num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)  # :1050
         cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
+        added_cond_kwargs = None
+        if ip_adapter_image_embeds is not None:                                                              # :1069-1082
+            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt, cfg)
+            added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
+        self._added_cond_kwargs = added_cond_kwargs
         if fused is None:
             fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg
         if fused:
@@ -248,7 +309,9 @@ class StableDiffusionPipeline:
             # CompVisDenoiser.forward broadcasts sigma[B] against 2B rows (external_k_diffusion.py:109-114), which
             # only works for B == 1 in the reference; repeat sigma per row so that B > 1 works too
             sig_rows = torch.cat([sigma] * 2) if cfg else sigma
-            noise_pred = kdm(latent_model_input, sig_rows, cond=text, cross_attention_kwargs=cross_attention_kwargs)
+            extra_kw = {} if self._added_cond_kwargs is None else {"added_cond_kwargs": self._added_cond_kwargs}
+            noise_pred = kdm(latent_model_input, sig_rows, cond=text, cross_attention_kwargs=cross_attention_kwargs,
+                             **extra_kw)
             if cfg:
                 u, c = noise_pred.chunk(2)
                 noise_pred = u + guidance_scale * (c - u)
@@ -266,7 +329,11 @@ class StableDiffusionPipeline:
         tables) and replays the same graph."""
         st = self._graphs.get(key)
         comp_cpu = self._compress_tables(region_state)
+        ack = self._added_cond_kwargs
         if st is not None and (st["compressed"] is None) == (comp_cpu is None):
+            if ack is not None:
+                for dst, src in zip(st["image_embeds"], ack["image_embeds"]):
+                    dst.copy_(src)
             st["text"].copy_(text)
             self._refresh_text_kv(st["text"])
             self._upload_tables(st, comp_cpu, region_state)
@@ -279,6 +346,7 @@ class StableDiffusionPipeline:
             "sigma": torch.ones(1, device=dev, dtype=torch.float32),
             "text": text.clone(),
             "compressed": None, "region_state": region_state,
+            "image_embeds": None if ack is None else [e.clone() for e in ack["image_embeds"]],
         }
         if comp_cpu is not None:
             st["compressed"] = {L: (ids.to(dev), rws.to(dev)) for L, (ids, rws) in comp_cpu.items()}
@@ -287,8 +355,10 @@ class StableDiffusionPipeline:
         kw["region_prompt"] = {"region_state": region_state, "compressed": st["compressed"], "sigma": st["sigma"],
                                "weight_func": weight_func, "n_std_groups": n_img}
 
+        ukw = {} if ack is None else {"added_cond_kwargs": {"image_embeds": st["image_embeds"]}}
+
         def step():
-            return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw).sample
+            return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw, **ukw).sample
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -368,8 +438,11 @@ class StableDiffusionPipeline:
         coeffs = sampling.dpmpp_2m_coefficients(sig)
         levels = tuple(sorted((int(L), tuple(w.shape)) for L, w in region_state.items())) \
             if isinstance(region_state, dict) else None
+        ack = getattr(self, "_added_cond_kwargs", None)
+        ip_key = None if ack is None else (tuple(tuple(e.shape) for e in ack["image_embeds"]),
+                                           id(getattr(self.unet, "encoder_hid_proj", None)))
         key = (n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
-               if hasattr(weight_func, "__code__") else id(weight_func))
+               if hasattr(weight_func, "__code__") else id(weight_func), ip_key)
         st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs)
         x = latents.contiguous().clone()
         old = torch.zeros_like(x)

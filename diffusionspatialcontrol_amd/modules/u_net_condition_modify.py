@@ -29,13 +29,96 @@ from .. import ops
 from .attention_modify import AttnProcessor2_0
 
 
+class ImageProjection(nn.Module):
+    """diffusers 0.27.2 `ImageProjection` [recalled; package absent - parity unpinned]: CLIP image embedding
+    [B, image_embed_dim] -> `num_image_text_embeds` context tokens [B, T, cross_attention_dim] (Linear + LayerNorm)."""
+
+    def __init__(self, image_embed_dim=768, cross_attention_dim=768, num_image_text_embeds=32):
+        super().__init__()
+        self.num_image_text_embeds = num_image_text_embeds
+        self.image_embeds = nn.Linear(image_embed_dim, num_image_text_embeds * cross_attention_dim)
+        self.norm = nn.LayerNorm(cross_attention_dim)
+
+    def forward(self, image_embeds):
+        b = image_embeds.shape[0]
+        return self.norm(self.image_embeds(image_embeds).reshape(b, self.num_image_text_embeds, -1))
+
+
+class MultiIPAdapterImageProjection(nn.Module):
+    """diffusers 0.27.2 `MultiIPAdapterImageProjection` [recalled]: one projection layer per loaded IP-Adapter; takes the
+    list of per-adapter image embeddings ([B, num_images, D], or the deprecated single [B, D] tensor) and returns the
+    list of per-adapter token tensors the IP-Adapter processors consume."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.image_projection_layers = nn.ModuleList(layers)
+
+    def forward(self, image_embeds):
+        if not isinstance(image_embeds, (list, tuple)):
+            image_embeds = [image_embeds.unsqueeze(1)]
+        if len(image_embeds) != len(self.image_projection_layers):
+            raise ValueError(f"image_embeds must have the same length as image_projection_layers, got {len(image_embeds)} "
+                             f"and {len(self.image_projection_layers)}")
+        out = []
+        for e, layer in zip(image_embeds, self.image_projection_layers):
+            b, n = e.shape[0], e.shape[1]
+            t = layer(e.reshape((b * n,) + tuple(e.shape[2:])))
+            out.append(t.reshape((b, n * t.shape[1]) + tuple(t.shape[2:])))      # [B, num_images * T, ctx]
+        return out
+
+
 class UNet2DConditionLoadersMixin_modify:
-    """Defined nowhere in the reference tree although imported at u_net_condition_modify.py:23; the IP-Adapter
-    loader calls `_load_ip_adapter_weights` on it (ip_adapter.py:231).  IP-Adapter is outside the hot path
-    (SURVEY.md 8f rank 2): the hook exists so the import surface resolves, and says so when used."""
+    """The symbol reference `u_net_condition_modify.py:23,70` imports but never defines; the reference's IP-Adapter
+    loader calls `_load_ip_adapter_weights` on it (ip_adapter.py:231) and expects the extra (FaceID) LoRAs back."""
+
+    def _convert_ip_adapter_image_proj_to_diffusers(self, state_dict):
+        """standard IP-Adapter image projection only ("proj.weight" + "norm.*": Linear + LayerNorm -> 4 tokens); the
+        Plus / Full / FaceID resamplers are further 'next' rows"""
+        if "proj.weight" not in state_dict:
+            raise NotImplementedError("only the standard IP-Adapter image projection (proj + norm) is built; the "
+                                      "Resampler / Full / FaceID projections are not")
+        num_tokens = 4
+        w = state_dict["proj.weight"]
+        ctx = w.shape[0] // num_tokens
+        proj = ImageProjection(image_embed_dim=w.shape[1], cross_attention_dim=ctx, num_image_text_embeds=num_tokens)
+        proj.load_state_dict({"image_embeds.weight": w, "image_embeds.bias": state_dict["proj.bias"],
+                              "norm.weight": state_dict["norm.weight"], "norm.bias": state_dict["norm.bias"]})
+        return proj, num_tokens
 
     def _load_ip_adapter_weights(self, state_dicts, low_cpu_mem_usage=False):
-        raise NotImplementedError("IP-Adapter weights are outside the MI355X hot path built so far")
+        """Installs IPAdapterAttnProcessor2_0 on every cross-attention layer (self-attention keeps AttnProcessor2_0) and
+        the image projection(s) as `encoder_hid_proj` [diffusers 0.27.2 `UNet2DConditionLoadersMixin` behaviour, recalled].
+        state_dicts: one {"image_proj": {...}, "ip_adapter": {"<id>.to_k_ip.weight", "<id>.to_v_ip.weight"}} per adapter;
+        ids 1, 3, 5, ... number the cross-attention layers in the order down_blocks, up_blocks, mid_block (the
+        registration order of diffusers' UNet, which the published IP-Adapter checkpoints follow)."""
+        from .attention_modify import AttnProcessor2_0, IPAdapterAttnProcessor2_0
+        if not isinstance(state_dicts, list):
+            state_dicts = [state_dicts]
+        projs, num_tokens = [], []
+        for sd in state_dicts:
+            pr, nt = self._convert_ip_adapter_image_proj_to_diffusers(sd["image_proj"])
+            projs.append(pr)
+            num_tokens.append(nt)
+        order = [(n, m) for pre in ("down_blocks", "up_blocks", "mid_block")
+                 for n, m in self.named_modules() if isinstance(m, Attention) and n.startswith(pre)]
+        key_id = 1
+        ref = next(self.parameters())
+        for name, attn in order:
+            if not attn.is_cross_attention:
+                attn.set_processor(AttnProcessor2_0())
+                continue
+            proc = IPAdapterAttnProcessor2_0(hidden_size=attn.inner_dim, cross_attention_dim=self.cfg.cross_attention_dim,
+                                             num_tokens=num_tokens, scale=1.0)
+            sd = {}
+            for i, s in enumerate(state_dicts):
+                sd[f"to_k_ip.{i}.weight"] = s["ip_adapter"][f"{key_id}.to_k_ip.weight"]
+                sd[f"to_v_ip.{i}.weight"] = s["ip_adapter"][f"{key_id}.to_v_ip.weight"]
+            proc.load_state_dict(sd)
+            attn.set_processor(proc.to(device=ref.device, dtype=ref.dtype))
+            key_id += 2
+        self.encoder_hid_proj = MultiIPAdapterImageProjection(projs).to(device=ref.device, dtype=ref.dtype)
+        self.config["encoder_hid_dim_type"] = "ip_image_proj"
+        return {}
 
 
 @dataclass
@@ -483,6 +566,12 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
             for conv in (self.conv_in, self.conv_out):
                 conv.weight.data = conv.weight.data.contiguous()
             self._channels_last = True
+        if getattr(self, "encoder_hid_proj", None) is not None and self.config.get("encoder_hid_dim_type") == "ip_image_proj":
+            # reference :1030-1037 - the IP-Adapter image tokens travel with the text as a tuple
+            if added_cond_kwargs is None or "image_embeds" not in added_cond_kwargs:
+                raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
+                                 "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
+            encoder_hidden_states = (encoder_hidden_states, self.encoder_hid_proj(added_cond_kwargs.get("image_embeds")))
         x = self.conv_in(sample.contiguous()).contiguous(memory_format=torch.channels_last)
         tadd = self._all_temb_adds(temb_act)
         skips = [x]

@@ -65,7 +65,7 @@ def region_attention(q, k, v, w, sigma, scale=None, attn_mask=None, n_std_groups
     return f(p @ v)                                                 # :103
 
 
-def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain):
+def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain, ip_branch=None):
     residual = hidden_states                                        # :425
     img_sequence_length = hidden_states.shape[1]                    # :427 (dim 1 also for 4-D input)
     input_ndim = hidden_states.ndim
@@ -88,6 +88,8 @@ def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core
     else:
         o = core_plain(qh, kh, vh)
     o = o.transpose(1, 2).reshape(B, -1, H * d)                     # :487
+    if ip_branch is not None:
+        o = ip_branch(o, qh, B, H, d)                               # :649-683 / :354-384: before the out projection
     o = attn.to_out[1](attn.to_out[0](o))                           # :491-493
     if input_ndim == 4:
         o = o.transpose(-1, -2).reshape(b, c, hh, ww)               # :495-496
@@ -128,3 +130,100 @@ def attn_processor(attn, hidden_states, encoder_hidden_states=None, region_promp
         return torch.softmax((q @ k.transpose(-2, -1)) * attn.scale, dim=-1) @ v   # :187-188
 
     return _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain)
+
+
+# ----------------------------------------------------------------------------- IP-Adapter processors
+def split_ip_hidden_states(encoder_hidden_states, num_tokens):
+    """attention_modify.py:560-577 / :268-282: `(text, [image tokens per adapter])`, or the deprecated single tensor whose
+    last num_tokens[0] rows are the (single) adapter's image tokens."""
+    if isinstance(encoder_hidden_states, tuple):
+        return encoder_hidden_states
+    end_pos = encoder_hidden_states.shape[1] - num_tokens[0]
+    return encoder_hidden_states[:, :end_pos, :], [encoder_hidden_states[:, end_pos:, :]]
+
+
+def ip_mask_downsample(mask, batch_size, num_queries, value_embed_dim):
+    """diffusers 0.27.2 `IPAdapterMaskProcessor.downsample` (called at attention_modify.py:672-675, :373-376).  The
+    package is absent from /root/reference and from this image: restated from the published algorithm - PARITY UNPINNED.
+    mask [1, h, w] -> [batch_size, num_queries, value_embed_dim]: bicubic resize to the query grid that keeps the
+    mask's aspect ratio, flatten, pad / truncate to num_queries, broadcast over the channels."""
+    o_h, o_w = mask.shape[1], mask.shape[2]
+    ratio = o_w / o_h
+    mask_h = int(math.sqrt(num_queries / ratio))
+    mask_h = int(mask_h) + int((num_queries % int(mask_h)) != 0)
+    mask_w = num_queries // mask_h
+    m = torch.nn.functional.interpolate(mask.unsqueeze(0), size=(mask_h, mask_w), mode="bicubic").squeeze(0)
+    if m.shape[0] < batch_size:
+        m = m.repeat(batch_size, 1, 1)
+    m = m.view(m.shape[0], -1)
+    area = mask_h * mask_w
+    if area < num_queries:
+        m = torch.nn.functional.pad(m, (0, num_queries - m.shape[1]), value=0.0)
+    if area > num_queries:
+        m = m[:, :num_queries]
+    return m.view(m.shape[0], m.shape[1], 1).repeat(1, 1, value_embed_dim)
+
+
+def _ip_branch(ip, attn, ip_hidden_states, ip_adapter_masks, scale_of):
+    """:636-683 / :341-384 - validation of the masks, then per adapter: K/V projections of the image tokens, plain
+    softmax attention of the SAME queries over them, optional mask multiply, `hidden += scale * ip_out`."""
+    if ip_adapter_masks is not None:
+        if not isinstance(ip_adapter_masks, torch.Tensor) or ip_adapter_masks.ndim != 4:
+            raise ValueError("ip_adapter_mask should be a tensor with shape [num_ip_adapter, 1, height, width].")
+        if len(ip_adapter_masks) != len(ip.scale):
+            raise ValueError("Number of ip_adapter_masks must match number of IP-Adapters")
+    else:
+        ip_adapter_masks = [None] * len(ip.scale)
+
+    def branch(o, qh, B, H, d):
+        for cur, sc, to_k_ip, to_v_ip, mask in zip(ip_hidden_states, ip.scale, ip.to_k_ip, ip.to_v_ip, ip_adapter_masks):
+            k = to_k_ip(cur).view(B, -1, H, d).transpose(1, 2)
+            v = to_v_ip(cur).view(B, -1, H, d).transpose(1, 2)
+            a = torch.softmax((qh @ k.transpose(-2, -1)) * scale_of(d), dim=-1) @ v      # :661-663 SDPA / :362-363
+            a = a.transpose(1, 2).reshape(B, -1, H * d)
+            if mask is not None:
+                a = a * ip_mask_downsample(mask, B, a.shape[1], a.shape[2]).to(a.dtype)
+            o = o + sc * a                                                               # :683 / :384
+        return o
+    return branch
+
+
+def ip_adapter_attn_processor2_0(ip, attn, hidden_states, encoder_hidden_states=None, region_prompt=None,
+                                 ip_adapter_masks=None):
+    """IPAdapterAttnProcessor2_0.__call__ (:547-700).  `ip` carries num_tokens, scale (list), to_k_ip, to_v_ip."""
+    text, ip_hidden_states = split_ip_hidden_states(encoder_hidden_states, ip.num_tokens)
+    branch = _ip_branch(ip, attn, ip_hidden_states, ip_adapter_masks, lambda d: 1.0 / math.sqrt(d))
+
+    def core_region(q, k, v, w, sigma, weight_func):
+        d = q.shape[-1]
+        a = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(d))
+        Bc, H, L, S = a.shape
+        flat = a.reshape(-1, L, S)
+        cw = weight_func(w, sigma, flat)
+        flat = flat + torch.repeat_interleave(cw, flat.shape[0] // cw.shape[0], dim=0)
+        return torch.softmax(flat.reshape(Bc, H, L, S), dim=-1) @ v
+
+    def core_plain(q, k, v):
+        return torch.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(q.shape[-1])), dim=-1) @ v
+
+    return _proc_common(attn, hidden_states, text, region_prompt, core_region, core_plain, ip_branch=branch)
+
+
+def ip_adapter_attn_processor(ip, attn, hidden_states, encoder_hidden_states=None, region_prompt=None,
+                              ip_adapter_masks=None):
+    """IPAdapterAttnProcessor.__call__ (:247-404): the same through baddbmm/bmm with alpha = attn.scale."""
+    text, ip_hidden_states = split_ip_hidden_states(encoder_hidden_states, ip.num_tokens)
+    branch = _ip_branch(ip, attn, ip_hidden_states, ip_adapter_masks, lambda d: attn.scale)
+
+    def core_region(q, k, v, w, sigma, weight_func):
+        a = (q @ k.transpose(-2, -1)) * attn.scale
+        Bc, H, L, S = a.shape
+        flat = a.reshape(-1, L, S)
+        cw = weight_func(w, sigma, flat)
+        flat = flat + torch.repeat_interleave(cw, flat.shape[0] // cw.shape[0], dim=0)
+        return torch.softmax(flat.reshape(Bc, H, L, S), dim=-1) @ v
+
+    def core_plain(q, k, v):
+        return torch.softmax((q @ k.transpose(-2, -1)) * attn.scale, dim=-1) @ v
+
+    return _proc_common(attn, hidden_states, text, region_prompt, core_region, core_plain, ip_branch=branch)

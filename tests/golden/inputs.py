@@ -60,6 +60,20 @@ def proc_inputs():
     return p
 
 
+def ip_inputs():
+    """IP-Adapter operands on top of proc_inputs(): two adapters (4 and 16 image tokens, scales 0.6 / 1.1) with their
+    to_k_ip / to_v_ip weights ([C, ctx], bias-free like attention_modify.py:241-246,545-550)."""
+    rng = _rng("ip")
+    p = proc_inputs()
+    C, ctx = p["C"], p["ctx"]
+    q = {"num_tokens": (4, 16), "scale": [0.6, 1.1]}
+    for i, T in enumerate(q["num_tokens"]):
+        q[f"ip{i}"] = _h(rng.standard_normal((2, T, ctx)))
+        q[f"wk_ip{i}"] = _h(rng.standard_normal((C, ctx)) / np.sqrt(ctx))
+        q[f"wv_ip{i}"] = _h(rng.standard_normal((C, ctx)) / np.sqrt(ctx))
+    return q
+
+
 # ----------------------------------------------------------------------------- region encoder inputs
 _VOCAB = {}
 

@@ -36,7 +36,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from inputs import attn_inputs, proc_inputs, region_state_inputs, FakeTokenizer  # noqa: E402
+from inputs import attn_inputs, proc_inputs, ip_inputs, region_state_inputs, FakeTokenizer  # noqa: E402
 
 REF = "/root/reference/source/modules"
 
@@ -227,6 +227,34 @@ def capture_processors(am, wf):
     print("processors.npz", {k: np.shape(v) for k, v in out.items()})
 
 
+def capture_ip_processors(am, wf):
+    """IPAdapterAttnProcessor2_0 (:506-700) and IPAdapterAttnProcessor (:208-404) on cross-attention: the text branch
+    (region / no region) plus two image-prompt branches added with their scales.  `ip_adapter_masks=None` only: the
+    mask branch calls diffusers' IPAdapterMaskProcessor.downsample, which is absent here (parity unpinned)."""
+    out = {}
+    p, q = proc_inputs(), ip_inputs()
+    L = p["L"]
+    hs, enc = torch.from_numpy(p["hidden"]), torch.from_numpy(p["enc"])
+    ips = [torch.from_numpy(q["ip0"]), torch.from_numpy(q["ip1"])]
+    sigma = torch.tensor(2.5)
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": sigma, "weight_func": wf}
+    attn = DuckAttn(p)
+    for pname, cls in (("ip2", am.IPAdapterAttnProcessor2_0), ("ip1", am.IPAdapterAttnProcessor)):
+        proc = cls(hidden_size=p["C"], cross_attention_dim=p["ctx"], num_tokens=q["num_tokens"], scale=list(q["scale"]))
+        with torch.no_grad():
+            for i in range(2):
+                proc.to_k_ip[i].weight.copy_(torch.from_numpy(q[f"wk_ip{i}"]))
+                proc.to_v_ip[i].weight.copy_(torch.from_numpy(q[f"wv_ip{i}"]))
+            out[pname + "/cross_region"] = proc(attn, hs, encoder_hidden_states=(enc, ips), region_prompt=rp).numpy()
+            out[pname + "/cross_noregion"] = proc(attn, hs, encoder_hidden_states=(enc, ips)).numpy()
+            # deprecated form: ONE tensor whose last num_tokens[0] rows are the image tokens (:568-577); only the
+            # first adapter takes part (zip stops at the shortest list)
+            cat = torch.cat([enc, ips[0]], dim=1)
+            out[pname + "/cross_region_cat"] = proc(attn, hs, encoder_hidden_states=cat, region_prompt=rp).numpy()
+    np.savez_compressed(os.path.join(HERE, "ip_processors.npz"), **out)
+    print("ip_processors.npz", {k: np.shape(v) for k, v in out.items()})
+
+
 def capture_region_encoder(er):
     out = {}
     for name, (state, ids, W, H, nimg) in region_state_inputs().items():
@@ -309,6 +337,7 @@ def main():
     wf = ref_weight_func()
     capture_attention(am, wf)
     capture_processors(am, wf)
+    capture_ip_processors(am, wf)
     capture_region_encoder(er)
     capture_denoiser(ek)
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from inputs import FakeTokenizer, attn_inputs, proc_inputs, region_state_inputs
+from inputs import FakeTokenizer, attn_inputs, ip_inputs, proc_inputs, region_state_inputs
 from oracle import k_diffusion_ref as kd
 from oracle import region_attention as ra
 from oracle import region_encoder as re_
@@ -110,6 +110,47 @@ def test_processors(pname, fn):
     # the table is looked up by hidden_states.shape[1]: a missing key is a KeyError (attention_modify.py:481)
     with pytest.raises(KeyError):
         fn(attn, hs, enc, dict(rp, region_state={L + 1: torch.from_numpy(p["w"])}))
+
+
+class DuckIP:
+    """num_tokens / scale / to_k_ip / to_v_ip of the reference's IP-Adapter processors (attention_modify.py:224-246)"""
+
+    def __init__(self, q):
+        self.num_tokens, self.scale = q["num_tokens"], list(q["scale"])
+        lin = lambda w: (lambda x: torch.nn.functional.linear(x, torch.from_numpy(w)))  # noqa: E731
+        self.to_k_ip = [lin(q[f"wk_ip{i}"]) for i in range(len(self.num_tokens))]
+        self.to_v_ip = [lin(q[f"wv_ip{i}"]) for i in range(len(self.num_tokens))]
+
+
+@pytest.mark.parametrize("pname,fn", [("ip2", ra.ip_adapter_attn_processor2_0), ("ip1", ra.ip_adapter_attn_processor)])
+def test_ip_adapter_processors(pname, fn):
+    """the oracle's IP-Adapter restatement against outputs of the reference's two IP-Adapter processors"""
+    g = load("ip_processors.npz")
+    p, q = proc_inputs(), ip_inputs()
+    L = p["L"]
+    hs, enc = torch.from_numpy(p["hidden"]), torch.from_numpy(p["enc"])
+    ips = [torch.from_numpy(q["ip0"]), torch.from_numpy(q["ip1"])]
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": torch.tensor(2.5), "weight_func": ra.default_weight_func}
+    attn, ip = DuckAttn(p), DuckIP(q)
+    tol = dict(atol=3e-5, rtol=0)
+    np.testing.assert_allclose(fn(ip, attn, hs, (enc, ips), rp).numpy(), g[pname + "/cross_region"], **tol)
+    np.testing.assert_allclose(fn(ip, attn, hs, (enc, ips), None).numpy(), g[pname + "/cross_noregion"], **tol)
+    cat = torch.cat([enc, ips[0]], dim=1)
+    np.testing.assert_allclose(fn(ip, attn, hs, cat, rp).numpy(), g[pname + "/cross_region_cat"], **tol)
+    # the image branches matter: dropping them changes the result
+    base = ra.attn_processor2_0(attn, hs, enc, rp).numpy()
+    assert np.abs(base - g["ip2/cross_region"]).max() > 1e-2
+    # mask validation errors of the reference (:637-647)
+    with pytest.raises(ValueError):
+        fn(ip, attn, hs, (enc, ips), rp, ip_adapter_masks=torch.ones(2, 8, 8))
+    with pytest.raises(ValueError):
+        fn(ip, attn, hs, (enc, ips), rp, ip_adapter_masks=torch.ones(3, 1, 8, 8))
+    # all-ones masks are the identity, zero masks remove the image branch (the downsample itself is parity-unpinned)
+    o1 = fn(ip, attn, hs, (enc, ips), rp, ip_adapter_masks=torch.ones(2, 1, 16, 16)).numpy()
+    np.testing.assert_allclose(o1, g[pname + "/cross_region"], atol=1e-4, rtol=0)
+    o0 = fn(ip, attn, hs, (enc, ips), rp, ip_adapter_masks=torch.zeros(2, 1, 16, 16)).numpy()
+    ref0 = (ra.attn_processor2_0 if pname == "ip2" else ra.attn_processor)(attn, hs, enc, rp).numpy()
+    np.testing.assert_allclose(o0, ref0, atol=3e-5, rtol=0)
 
 
 def test_processor_variants_agree():

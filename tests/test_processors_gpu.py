@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from inputs import attn_inputs, proc_inputs
+from inputs import attn_inputs, ip_inputs, proc_inputs
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -45,6 +45,69 @@ class DuckAttn:
         self.to_k = lin(p["wk_self"] if self_kv else p["wk"])
         self.to_v = lin(p["wv_self"] if self_kv else p["wv"])
         self.to_out = nn.ModuleList([lin(p["wo"], p["bo"]), nn.Dropout(0.0)])
+
+
+@pytest.mark.parametrize("pname", ["ip2", "ip1"])
+def test_ip_adapter_processors_against_reference_goldens(mods, pname):
+    """IPAdapterAttnProcessor2_0 / IPAdapterAttnProcessor vs the reference's own outputs"""
+    ops, am = mods
+    from oracle import region_attention as ra
+    g = np.load(os.path.join(G, "ip_processors.npz"))
+    p, q = proc_inputs(), ip_inputs()
+    L = p["L"]
+    cls = am.IPAdapterAttnProcessor2_0 if pname == "ip2" else am.IPAdapterAttnProcessor
+    proc = cls(hidden_size=p["C"], cross_attention_dim=p["ctx"], num_tokens=q["num_tokens"], scale=list(q["scale"]))
+    assert sorted(proc.state_dict().keys()) == ["to_k_ip.0.weight", "to_k_ip.1.weight", "to_v_ip.0.weight", "to_v_ip.1.weight"]
+    proc.load_state_dict({f"to_{kv}_ip.{i}.weight": torch.from_numpy(q[f"w{kv}_ip{i}"]) for kv in "kv" for i in range(2)})
+    proc = proc.half().cuda()
+    hs, enc = torch.from_numpy(p["hidden"]).half().cuda(), torch.from_numpy(p["enc"]).half().cuda()
+    ips = [torch.from_numpy(q["ip0"]).half().cuda(), torch.from_numpy(q["ip1"]).half().cuda()]
+    wf = lambda w, sigma, qk: w * sigma * qk.std()       # noqa: E731
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": torch.tensor(2.5), "weight_func": wf}
+    attn = DuckAttn(p)
+
+    def check(out, key, tol=TOL):
+        err = np.abs(out.float().cpu().numpy() - g[f"{pname}/{key}"])
+        assert err.max() < tol, (key, err.max())
+
+    with torch.no_grad():
+        check(proc(attn, hs, encoder_hidden_states=(enc, ips), region_prompt=rp), "cross_region")
+        check(proc(attn, hs, encoder_hidden_states=(enc, ips)), "cross_noregion")
+        check(proc(attn, hs, encoder_hidden_states=torch.cat([enc, ips[0]], dim=1), region_prompt=rp), "cross_region_cat")
+        with pytest.raises(ValueError):
+            proc(attn, hs, encoder_hidden_states=(enc, ips), region_prompt=rp, ip_adapter_masks=torch.ones(2, 8, 8).cuda())
+        with pytest.raises(ValueError):
+            proc(attn, hs, encoder_hidden_states=(enc, ips), region_prompt=rp, ip_adapter_masks=torch.ones(3, 1, 8, 8).cuda())
+        # masks: ones = identity; a half-plane mask against the oracle's restatement (downsample parity-unpinned)
+        ones = torch.ones(2, 1, 16, 16).cuda()
+        check(proc(attn, hs, encoder_hidden_states=(enc, ips), region_prompt=rp, ip_adapter_masks=ones), "cross_region", 8e-3)
+        half = torch.zeros(2, 1, 16, 16)
+        half[0, :, :, :8] = 1.0
+        half[1, :, 8:, :] = 1.0
+        out = proc(attn, hs, encoder_hidden_states=(enc, ips), region_prompt=rp, ip_adapter_masks=half.cuda())
+
+        class DuckIP:
+            num_tokens, scale = q["num_tokens"], list(q["scale"])
+            to_k_ip = [lambda x, i=i: torch.nn.functional.linear(x, torch.from_numpy(q[f"wk_ip{i}"])) for i in range(2)]
+            to_v_ip = [lambda x, i=i: torch.nn.functional.linear(x, torch.from_numpy(q[f"wv_ip{i}"])) for i in range(2)]
+
+        class CpuAttn:
+            heads, scale = p["H"], (p["C"] // p["H"]) ** -0.5
+            residual_connection, rescale_output_factor = False, 1.0
+            to_q = staticmethod(lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wq"])))
+            to_k = staticmethod(lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wk"])))
+            to_v = staticmethod(lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wv"])))
+            to_out = [lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wo"]), torch.from_numpy(p["bo"])), lambda x: x]
+
+        fn = ra.ip_adapter_attn_processor2_0 if pname == "ip2" else ra.ip_adapter_attn_processor
+        rp_cpu = dict(rp, weight_func=ra.default_weight_func)
+        ref = fn(DuckIP, CpuAttn, torch.from_numpy(p["hidden"]), (torch.from_numpy(p["enc"]), [torch.from_numpy(q["ip0"]), torch.from_numpy(q["ip1"])]),
+                 rp_cpu, ip_adapter_masks=half)
+        assert (out.float().cpu() - ref).abs().max().item() < 8e-3
+        # a self-attention call (no encoder states) passes through the text-less path
+        o_self = proc(DuckAttn(p, self_kv=True), hs, region_prompt=rp)
+        g0 = np.load(os.path.join(G, "processors.npz"))
+        assert np.abs(o_self.float().cpu().numpy() - g0["p2/self" if pname == "ip2" else "p1/self"]).max() < TOL
 
 
 @pytest.mark.parametrize("pname", ["p2", "p1"])

@@ -490,3 +490,66 @@ def test_vae_decoder_full_size(ops):
     with torch.no_grad():
         y = vae.decode(z).sample
     assert y.shape == (1, 3, 512, 512) and torch.isfinite(y).all()
+
+
+def test_ip_adapter_unet_and_pipeline(ops):
+    """IP-Adapter weights load into the UNet with the published key numbering (cross-attention
+    layers numbered 1, 3, 5, ... over down_blocks, up_blocks, mid_block), the image tokens reach every cross-attention
+    processor as the reference's (text, [tokens]) tuple, scale 0 is the identity, and fused == protocol mode."""
+    from diffusionspatialcontrol_amd.modules import u_net_condition_modify as um, attention_modify as am
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import StableDiffusionPipeline
+    torch.manual_seed(0)
+    cfg = um.UNetConfig.tiny()
+    unet = um.UNet2DConditionModel(cfg).half().cuda().eval()
+    ctx = cfg.cross_attention_dim
+    cross = [(n, m) for pre in ("down_blocks", "up_blocks", "mid_block") for n, m in unet.named_modules()
+             if isinstance(m, um.Attention) and m.is_cross_attention and n.startswith(pre)]
+    g = torch.Generator().manual_seed(3)
+    emb_dim = 48
+    sd = {"image_proj": {"proj.weight": torch.randn(4 * ctx, emb_dim, generator=g) * 0.1, "proj.bias": torch.zeros(4 * ctx),
+                         "norm.weight": torch.ones(ctx), "norm.bias": torch.zeros(ctx)}, "ip_adapter": {}}
+    for i, (n, m) in enumerate(cross):
+        sd["ip_adapter"][f"{2 * i + 1}.to_k_ip.weight"] = torch.randn(m.inner_dim, ctx, generator=g) * 0.2 + i
+        sd["ip_adapter"][f"{2 * i + 1}.to_v_ip.weight"] = torch.randn(m.inner_dim, ctx, generator=g) * 0.2
+    x = torch.randn(2, 4, 16, 16, generator=g).half().cuda()
+    text = torch.randn(2, 77, ctx, generator=g).half().cuda()
+    t = torch.tensor([500.0, 500.0]).cuda()
+    with torch.no_grad():
+        base = unet(x, t, encoder_hidden_states=text).sample
+        assert unet._load_ip_adapter_weights([sd]) == {}
+        procs = unet.attn_processors
+        assert sum(isinstance(p, am.IPAdapterAttnProcessor2_0) for p in procs.values()) == len(cross)
+        assert all(isinstance(p, am.AttnProcessor2_0) for n, p in procs.items() if ".attn1." in n)
+        last = dict(unet.named_modules())[cross[-1][0]].processor           # the mid block carries the LAST key id
+        assert cross[-1][0].startswith("mid_block")
+        assert abs(last.to_k_ip[0].weight.float().mean().item() - (len(cross) - 1)) < 0.05
+        img = [torch.randn(2, 1, emb_dim, generator=g).half().cuda()]
+        with pytest.raises(ValueError):
+            unet(x, t, encoder_hidden_states=text)                         # image_embeds required now (reference :1031-1034)
+        out = unet(x, t, encoder_hidden_states=text, added_cond_kwargs={"image_embeds": img}).sample
+        assert torch.isfinite(out).all() and (out - base).abs().max().item() > 1e-3
+        for p in procs.values():
+            if isinstance(p, am.IPAdapterAttnProcessor2_0):
+                p.scale = [0.0]
+        out0 = unet(x, t, encoder_hidden_states=text, added_cond_kwargs={"image_embeds": img}).sample
+        # identity up to the run-to-run noise of MIOpen's atomic convolutions at this toy resolution (see the loop test)
+        assert (out0 - base).abs().max().item() < 5e-3 < (out - base).abs().max().item()
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    pipe.set_ip_adapter_scale(0.7)
+    lat = torch.randn(1, 4, 16, 16, generator=g).half()
+    emb = torch.cat([torch.zeros_like(img[0][:1]), img[0][1:]])            # [negative; positive] along dim 0 (:207-215)
+    kw = dict(height=128, width=128, num_inference_steps=4, guidance_scale=5.0, output_type="latent",
+              sampler_name="sample_dpmpp_2m", sampler_opt={"scheduler": "karras"}, prompt_embeds=text[1:],
+              negative_prompt_embeds=text[:1], ip_adapter_image_embeds=[emb])
+    a = pipe.txt2img(None, fused=True, latents=lat.clone(), **kw)[0].float().cpu()
+    b = pipe.txt2img(None, fused=False, latents=lat.clone(), **kw)[0].float().cpu()
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 3e-2 * max(1.0, b.abs().max().item())
+    kw0 = dict(kw)
+    kw0.pop("ip_adapter_image_embeds")
+    with pytest.raises(ValueError):
+        pipe.txt2img(None, fused=False, latents=lat.clone(), **kw0)        # adapter loaded, no image embeddings
+    pipe.unload_ip_adapter()
+    assert unet.encoder_hid_proj is None and all(isinstance(p, am.AttnProcessor) for p in unet.attn_processors.values())
+    c = pipe.txt2img(None, fused=True, latents=lat.clone(), **kw0)[0].float().cpu()
+    assert torch.isfinite(c).all() and (c - a).abs().max().item() > 1e-3   # the image prompt did steer the result
