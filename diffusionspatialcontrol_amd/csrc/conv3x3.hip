@@ -354,14 +354,24 @@ int tile_width(int H, int W) {
     return 0;
 }
 
-int auto_splits(int tiles, int nc) {
-    // at most 2 workgroups per CU (512 slots); prefer an even division of the slices
-    int smax = 512 / tiles;
-    if (smax > nc) smax = nc;
-    if (smax <= 1) return 1;
-    for (int s = smax; s > 1; --s)
-        if (nc % s == 0) return s;
-    return 1;
+// Split count from a cost model fitted to tools/mb_conv3.py on MI355X (us):
+//   loop      9 * nc / S steps x 0.26 us, x1.15 once two workgroups share a CU (> 256), x wgs/512 beyond 512
+//   fixed     5 (launch, prologue, epilogue)
+//   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
+// e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
+int auto_splits(int tiles, int nc, long long npix, int cout) {
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= nc; ++s) {
+        if (nc % s != 0) continue;
+        const long long wgs = (long long)tiles * s;
+        if (s > 1 && wgs > 1024) break;
+        const double load = wgs <= 256 ? 1.0 : (wgs <= 512 ? 1.15 : 1.15 * (double)wgs / 512.0);
+        double t = 9.0 * nc / s * 0.26 * load + 5.0;
+        if (s > 1) t += 4.0 + (double)s * (double)npix * cout * 8.0 / 3.0e6;
+        if (t < best_t) { best_t = t; best = s; }
+    }
+    return best;
 }
 
 int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
@@ -373,7 +383,7 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
     const int nsb = 16 / tw;
     p->mt = (p->nblk + nsb - 1) / nsb; p->nt = Cout / BN;
     p->npix = (long long)B * H * W;
-    if (splits <= 0) splits = auto_splits(p->mt * p->nt, p->nc);
+    if (splits <= 0) splits = auto_splits(p->mt * p->nt, p->nc, p->npix, Cout);
     if (splits > p->nc) splits = p->nc;
     p->cps = (p->nc + splits - 1) / splits;
     p->splits = (p->nc + p->cps - 1) / p->cps;

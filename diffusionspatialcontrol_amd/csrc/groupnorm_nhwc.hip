@@ -182,6 +182,134 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
     }
 }
 
+// Medium images and group widths that are not multiples of 8 channels (the 32x32 / 16x16 UNet levels: 20, 30, 60
+// channels per group): ONE launch, one workgroup per (image, bundle), a bundle = the smallest run of groups whose
+// channels fill whole 16-byte vectors (lcm(cpg, 8) channels: 1, 2 or 4 groups).  Thread t owns vector t % nvec of the
+// pixels t / nvec, t / nvec + npl, ... (coalesced rows), keeps them PACKED in registers (NV x 4 VGPRs), and the
+// reductions run per channel -> fixed-order LDS tree over the pixel lanes -> per group: bit-reproducible.
+// Two-pass variance on the register copy, like gn_nhwc_small.
+struct GnBundle { int gb, nvec, npl; };          // groups per bundle, vectors per pixel of a bundle, pixel lanes
+
+template <int T, int NV>
+__global__ __launch_bounds__(T) void gn_nhwc_bundle(GnN p, GnBundle q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* S = reinterpret_cast<float*>(smem);                // [npl][nvec * 8] channel partials
+    __shared__ float gstat[8];                                // per group of the bundle: mean, then rstd
+    const int nb = p.G / q.gb;
+    const int b = blockIdx.x / nb, bun = blockIdx.x % nb;
+    const int cw = q.nvec * 8;                                // channels of a bundle
+    const int t = threadIdx.x;
+    const bool active = t < q.nvec * q.npl;
+    const int v = t % q.nvec, lp = t / q.nvec;
+    const long long base = (long long)b * p.HW * p.C + (long long)bun * cw + v * 8;
+    h8_t x[NV];
+    float ad[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ad[j] = 0.f;
+    if (active && p.add) {
+        const h8_t a = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + bun * cw + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ad[j] = (float)a[j];
+    }
+    float cs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int pix = lp + i * q.npl;
+        x[i] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        if (active && pix < p.HW) {
+            x[i] = *reinterpret_cast<const h8_t*>(p.x + base + (long long)pix * p.C);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += (float)x[i][j] + ad[j];
+        }
+    }
+    // fixed-order tree over the pixel lanes: S[lp][v*8 + j]
+    auto tree = [&](const float* mine) {
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) S[t * 8 + j] = mine[j];
+        }
+        __syncthreads();
+        int n = q.npl;
+        while (n > 1) {
+            const int half = (n + 1) >> 1;
+            if (active && lp + half < n) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) S[t * 8 + j] += S[(t + half * q.nvec) * 8 + j];
+            }
+            __syncthreads();
+            n = half;
+        }
+    };
+    tree(cs);
+    const float cnt = (float)p.HW * p.cpg;
+    if (t < q.gb) {
+        float a = 0.f;
+        for (int c = t * p.cpg; c < (t + 1) * p.cpg; ++c) a += S[c];      // row 0 of S = per-channel totals
+        gstat[t] = a / cnt;
+    }
+    __syncthreads();
+    float mj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mj[j] = gstat[(v * 8 + j) / p.cpg] - ad[j];   // (x + ad) - mean = x - mj
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int pix = lp + i * q.npl;
+        if (active && pix < p.HW) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)x[i][j] - mj[j]; cs[j] += d * d; }
+        }
+    }
+    tree(cs);
+    if (t < q.gb) {
+        float a = 0.f;
+        for (int c = t * p.cpg; c < (t + 1) * p.cpg; ++c) a += S[c];
+        gstat[4 + t] = rsqrtf(a / cnt + p.eps);
+    }
+    __syncthreads();
+    if (!active) return;
+    float sc[8], sh[8];
+    {
+        const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + bun * cw + v * 8);
+        const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + bun * cw + v * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc[j] = gstat[4 + (v * 8 + j) / p.cpg] * (float)ga[j];
+            sh[j] = (float)be[j] - mj[j] * sc[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int pix = lp + i * q.npl;
+        if (pix < p.HW) {
+            h8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)x[i][j] * sc[j] + sh[j];
+                if (p.silu) f = f / (1.f + __expf(-f));
+                o[j] = (half_t)f;
+            }
+            *reinterpret_cast<h8_t*>(p.y + base + (long long)pix * p.C) = o;
+        }
+    }
+}
+
+// bundle geometry for T threads and NV vectors per thread; false when the image does not fit
+bool bundle_plan(const GnN& p, int T, int NV, GnBundle* q) {
+    int gb = 1;
+    while ((gb * p.cpg) % 8 != 0) ++gb;                       // 1, 2, 4 or 8 groups
+    if (gb > 4 || p.G % gb != 0) return false;
+    q->gb = gb;
+    q->nvec = gb * p.cpg / 8;
+    if (q->nvec > T) return false;
+    q->npl = T / q->nvec;
+    return (long long)q->npl * NV >= p.HW;
+}
+
 bool plan(GnN& p) {
     p.cv = p.C / 8;
     if (p.C % 8 != 0 || p.cv > kMaxT || p.G > 64 || p.C % p.G != 0) return false;
@@ -261,6 +389,17 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     if (p.cpg % 8 == 0 && (long long)p.HW * (p.cpg / 8) <= 256 * kSmallVec) {      // small image: single launch
         hipLaunchKernelGGL(gn_nhwc_small, dim3(B * groups), dim3(256), 0, st, p);
         return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+    }
+    {
+        GnBundle q{};
+        if (bundle_plan(p, 256, 16, &q)) {
+            hipLaunchKernelGGL((gn_nhwc_bundle<256, 16>), dim3(B * (groups / q.gb)), dim3(256), (size_t)256 * 8 * sizeof(float), st, p, q);
+            return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+        }
+        if (bundle_plan(p, 1024, 16, &q)) {
+            hipLaunchKernelGGL((gn_nhwc_bundle<1024, 16>), dim3(B * (groups / q.gb)), dim3(1024), (size_t)1024 * 8 * sizeof(float), st, p, q);
+            return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+        }
     }
     const dim3 grid(B * p.nchunk), block(p.cv * p.k);
     hipLaunchKernelGGL(gn_nhwc_stats, grid, block, (size_t)2 * p.k * C * sizeof(float), st, p);

@@ -199,6 +199,31 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         const half_t* Kb = lds + buf * C::TILE_HALVES;
         const half_t* Vb = Kb + kKV * KP;
 
+        // ---- HOIST (head dims <= 64, where the registers allow it): all LDS reads of the tile go out first - a read
+        // issued right before its MFMA exposes the LDS latency at 1-2 waves per SIMD - K fragments for QK^T, then the
+        // V^T fragments, whose latency the QK^T MFMAs and the softmax cover
+        constexpr bool HOIST = NK <= 4;
+        auto k_frag = [&](int m, int ks) { return *reinterpret_cast<const h8_t*>(Kb + (32 * m + r) * KP + 16 * ks + 8 * hh); };
+        auto v_frag = [&](int dm, int tt) {
+            const half_t* vp = Vb + tr_off + (16 * tt) * VP + 32 * dm;
+            const h4_t lo = tr_read(vp);
+            const h4_t hi = tr_read(vp + 8 * VP);
+            return h8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        h8_t kf[HOIST ? 2 : 1][HOIST ? NK : 1];
+        h8_t vf[HOIST ? DM : 1][HOIST ? 4 : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) kf[m][ks] = k_frag(m, ks);
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
         // ---- S^T = K . Q^T  (2 row tiles of 32 keys); each K fragment feeds the QT query tiles
         f16x_t s[QT][2];
 #pragma unroll
@@ -211,9 +236,9 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
-                const h8_t kf = *reinterpret_cast<const h8_t*>(Kb + (32 * m + r) * KP + 16 * ks + 8 * hh);
+                const h8_t kfr = HOIST ? kf[HOIST ? m : 0][HOIST ? ks : 0] : k_frag(m, ks);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) s[qt][m] = mfma_32x32x16(kf, qf[qt][ks], s[qt][m]);
+                for (int qt = 0; qt < QT; ++qt) s[qt][m] = mfma_32x32x16(kfr, qf[qt][ks], s[qt][m]);
             }
 
         if (dbg) asm volatile("" :: "v"(s[0][0][0]), "v"(s[0][1][15]));
@@ -269,12 +294,9 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
         for (int dm = 0; dm < DM; ++dm) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const half_t* vp = Vb + tr_off + (16 * tt) * VP + 32 * dm;
-                const h4_t lo = tr_read(vp);
-                const h4_t hi = tr_read(vp + 8 * VP);
-                const h8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const h8_t vfr = HOIST ? vf[HOIST ? dm : 0][HOIST ? tt : 0] : v_frag(dm, tt);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) o[qt][dm] = mfma_32x32x16(vf, pf[qt][tt], o[qt][dm]);
+                for (int qt = 0; qt < QT; ++qt) o[qt][dm] = mfma_32x32x16(vfr, pf[qt][tt], o[qt][dm]);
             }
         }
         if (dbg) asm volatile("" :: "v"(o[0][0][0]), "v"(o[0][DM - 1][15]));

@@ -43,7 +43,12 @@ def test_groupnorm_silu(ops, B, C, h, w, G, act, eps):
                                                     (16, 640, 32, 32, 32, True, True), (3, 64, 5, 3, 8, False, True),
                                                     (2, 1920, 32, 32, 32, True, False), (2, 960, 64, 64, 32, True, True),
                                                     (2, 2560, 8, 8, 32, True, True), (2, 1280, 16, 16, 32, True, True),
-                                                    (2, 2560, 16, 16, 32, True, False), (4, 1280, 8, 8, 32, False, True)])
+                                                    (2, 2560, 16, 16, 32, True, False), (4, 1280, 8, 8, 32, False, True),
+                                                    # single-launch bundle kernel: 10 / 20 / 30 / 40 / 60 channels per group
+                                                    (2, 640, 32, 32, 32, True, True), (2, 960, 32, 32, 32, True, False),
+                                                    (2, 320, 32, 32, 32, False, True), (2, 1280, 32, 32, 32, True, True),
+                                                    (2, 1920, 16, 16, 32, True, True), (2, 640, 16, 16, 32, True, False),
+                                                    (3, 96, 24, 24, 8, True, True), (1, 48, 7, 9, 4, False, False)])
 def test_groupnorm_silu_nhwc(ops, B, C, h, w, G, act, with_add):
     g = torch.Generator().manual_seed(B * C + h + 1)
     x = (torch.randn(B, C, h, w, generator=g) * 1.7 + 0.6).half()
