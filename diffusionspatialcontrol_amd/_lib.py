@@ -55,6 +55,7 @@ _SIGNATURES = {
     "dsc_groupnorm_silu": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                                                              _vp, ctypes.c_size_t, _vp]),
     "dsc_groupnorm_nhwc_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "dsc_debug_set_gn_mode": (None, [ctypes.c_int]),
     "dsc_groupnorm_silu_nhwc": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64] + [ctypes.c_int] * 4 +
                                 [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "dsc_add_bias_residual": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),

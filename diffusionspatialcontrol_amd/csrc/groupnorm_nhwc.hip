@@ -6,7 +6,9 @@
 // workgroup), so every load/store is a coalesced 16-byte access and the per-channel constants stay in registers.
 //   launch 1 gn_nhwc_stats    : per-thread channel sums -> LDS [k][C] -> per-channel -> per-group (sum, sumsq) in
 //                               fp64 -> partials[b][chunk][g]
-//   launch 2 gn_nhwc_finalize : one wave per (image, group) adds the chunk partials (fixed order) -> (mean, rstd)[b][g].
+//   launch 2 gn_nhwc_finalize : one wave per (image, group) adds the chunk partials -> (mean, rstd)[b][g]; skipped for
+//                               tensors <= 3 MB, whose statistics pass is capped at 32 chunks per image so that
+//                               every apply workgroup can add the partials itself
 //                               Without it every apply workgroup re-read all nchunk x G partials (64 KB, more than
 //                               its own 40 KB of activations)
 //   launch 3 gn_nhwc_apply    : folds mean/rstd/gamma/beta(/add) into one scale+shift per channel, streams its rows:
@@ -23,7 +25,9 @@ struct GnN {
     const half_t* x; half_t* y; const half_t* gamma; const half_t* beta; const half_t* add;
     double* partials;            // [B][nchunk][G][2]
     float* stats;                // [B][G][2] (mean, rstd), behind the partials in the workspace
-    int B, HW, C, G, cpg, cv, k, nchunk, rows;
+    int B, HW, C, G, cpg, cv, k, nchunk, rows;       // statistics pass: nchunk row chunks of `rows` rows per image
+    int anchunk, arows;                               // apply pass: its own (finer) chunking
+    int inline_stats;                                 // 1: the apply workgroups reduce the chunk partials themselves (no finalize launch)
     long long add_stride;
     float eps; int silu;
 };
@@ -82,8 +86,31 @@ __global__ __launch_bounds__(64) void gn_nhwc_finalize(GnN p) {
 
 __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     __shared__ float mean_s[64], rstd_s[64];
-    const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
-    if (threadIdx.x < p.G) {
+    __shared__ double red[8 * 64 * 2];
+    const int b = blockIdx.x / p.anchunk, chunk = blockIdx.x % p.anchunk;
+    if (p.inline_stats) {
+        // few statistics chunks (<= 32 per image): every apply workgroup adds them itself, in a fixed order - 16 KB of
+        // L2 reads instead of a third launch.  thread (g, part): chunks part, part + P, ...; then the P parts in order
+        const int P = min(8, (int)blockDim.x / p.G);
+        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+        if (part < P) {
+            const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
+            double a1 = 0.0, a2 = 0.0;
+            for (int i = part; i < p.nchunk; i += P) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+            red[(part * 64 + g) * 2] = a1; red[(part * 64 + g) * 2 + 1] = a2;
+        }
+        __syncthreads();
+        if (threadIdx.x < p.G) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int q = 0; q < P; ++q) { t1 += red[(q * 64 + threadIdx.x) * 2]; t2 += red[(q * 64 + threadIdx.x) * 2 + 1]; }
+            const double n = (double)p.HW * p.cpg;
+            const double m = t1 / n;
+            double var = t2 / n - m * m;
+            var = var > 0.0 ? var : 0.0;
+            mean_s[threadIdx.x] = (float)m;
+            rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
+        }
+    } else if (threadIdx.x < p.G) {
         mean_s[threadIdx.x] = p.stats[((long long)b * p.G + threadIdx.x) * 2];
         rstd_s[threadIdx.x] = p.stats[((long long)b * p.G + threadIdx.x) * 2 + 1];
     }
@@ -102,7 +129,7 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
             sh[j] = (float)be[j] + ((float)ad[j] - mean_s[g]) * sc[j];
         }
     }
-    const int r0 = chunk * p.rows, r1 = min(r0 + p.rows, p.HW);
+    const int r0 = chunk * p.arows, r1 = min(r0 + p.arows, p.HW);
     const long long off = (long long)b * p.HW * p.C + c8 * 8;
     for (int row = r0 + slice; row < r1; row += p.k) {
         const h8_t v = *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C);
@@ -323,10 +350,23 @@ bool plan(GnN& p) {
     int nchunk = (p.HW + min_rows - 1) / min_rows;
     if (nchunk > target) nchunk = target;
     if (nchunk < 1) nchunk = 1;
-    p.rows = (p.HW + nchunk - 1) / nchunk;
-    p.nchunk = (p.HW + p.rows - 1) / p.rows;
+    p.arows = (p.HW + nchunk - 1) / nchunk;
+    p.anchunk = (p.HW + p.arows - 1) / p.arows;
+    // Small tensors (<= 3 MB): at most 32 statistics chunks per image and the apply workgroups add the partials
+    // themselves - two launches.  Larger ones keep the fine chunking (the statistics pass needs the whole chip) and the
+    // separate finalize launch (measured, tools/mb_gn.py: 640ch @64x64 18.1 us with three launches, 23.9 with two).
+    if ((long long)p.B * p.HW * p.C * 2 <= 3ll << 20) {
+        const int sch = p.anchunk < 32 ? p.anchunk : 32;
+        p.rows = (p.HW + sch - 1) / sch;
+        p.nchunk = (p.HW + p.rows - 1) / p.rows;
+        p.inline_stats = 1;
+    } else {
+        p.rows = p.arows; p.nchunk = p.anchunk; p.inline_stats = 0;
+    }
     return true;
 }
+
+int g_gn_mode = 0;   // diagnostics (dsc_debug_set_gn_mode): 0 auto, 2 never a single-launch kernel, 3 also the 1024-thread bundle kernel, 4 = 2 + separate finalize launch
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -359,11 +399,13 @@ extern "C" int dsc_add_bias_residual(const void* a, const void* b, const void* b
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
+extern "C" void dsc_debug_set_gn_mode(int mode) { g_gn_mode = mode; }
+
 extern "C" size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int groups) {
     GnN p{};
     p.B = B; p.C = C; p.HW = hw; p.G = groups;
     if (B <= 0 || C <= 0 || hw <= 0 || groups <= 0 || !plan(p)) return 0;
-    return (size_t)B * p.nchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
+    return (size_t)B * p.anchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
 }
 
 extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, const void* add,
@@ -376,34 +418,39 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     if (!plan(p)) return DSC_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta) || (add && (!al16(add) || add_row_stride % 8 != 0 || add_row_stride < C)))
         return DSC_ERR_UNSUPPORTED;
-    const size_t need = (size_t)B * p.nchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
+    const size_t need = (size_t)B * p.anchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;
     p.x = static_cast<const half_t*>(x); p.y = static_cast<half_t*>(y);
     p.gamma = static_cast<const half_t*>(gamma); p.beta = static_cast<const half_t*>(beta);
     p.add = static_cast<const half_t*>(add);
     p.add_stride = add_row_stride;
     p.partials = static_cast<double*>(workspace);
-    p.stats = reinterpret_cast<float*>(p.partials + (size_t)B * p.nchunk * groups * 2);
+    p.stats = reinterpret_cast<float*>(p.partials + (size_t)B * p.anchunk * groups * 2);
     p.eps = eps; p.silu = apply_silu;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (p.cpg % 8 == 0 && (long long)p.HW * (p.cpg / 8) <= 256 * kSmallVec) {      // small image: single launch
+    if (p.cpg % 8 == 0 && (long long)p.HW * (p.cpg / 8) <= 256 * kSmallVec && g_gn_mode != 2) {      // small image: single launch
         hipLaunchKernelGGL(gn_nhwc_small, dim3(B * groups), dim3(256), 0, st, p);
         return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
     }
     {
+        // one workgroup streams a whole (image, bundle) slab: it wins only while the slab is small (measured,
+        // tools/mb_gn.py: 1280 vectors 9.8 us vs 11.9 us for three launches; 3840 vectors 17.9 vs 12.6)
         GnBundle q{};
-        if (bundle_plan(p, 256, 16, &q)) {
+        if (g_gn_mode < 2 && bundle_plan(p, 256, 16, &q) && (long long)p.HW * q.nvec <= 1536) {
             hipLaunchKernelGGL((gn_nhwc_bundle<256, 16>), dim3(B * (groups / q.gb)), dim3(256), (size_t)256 * 8 * sizeof(float), st, p, q);
             return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
         }
-        if (bundle_plan(p, 1024, 16, &q)) {
+        if (g_gn_mode == 3 && bundle_plan(p, 1024, 16, &q)) {       // diagnostics only: slower than three launches
             hipLaunchKernelGGL((gn_nhwc_bundle<1024, 16>), dim3(B * (groups / q.gb)), dim3(1024), (size_t)1024 * 8 * sizeof(float), st, p, q);
             return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
         }
     }
-    const dim3 grid(B * p.nchunk), block(p.cv * p.k);
-    hipLaunchKernelGGL(gn_nhwc_stats, grid, block, (size_t)2 * p.k * C * sizeof(float), st, p);
-    hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(gn_nhwc_apply, grid, block, 0, st, p);
+    const dim3 block(p.cv * p.k);
+    if (g_gn_mode == 4) {                                        // diagnostics: the three-launch form
+        p.rows = p.arows; p.nchunk = p.anchunk; p.inline_stats = 0;
+    }
+    hipLaunchKernelGGL(gn_nhwc_stats, dim3(B * p.nchunk), block, (size_t)2 * p.k * C * sizeof(float), st, p);
+    if (!p.inline_stats) hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
+    hipLaunchKernelGGL(gn_nhwc_apply, dim3(B * p.anchunk), block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
