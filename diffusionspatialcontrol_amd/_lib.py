@@ -66,6 +66,8 @@ _SIGNATURES = {
     "dsc_conv3x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "dsc_conv3x3_nhwc_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 5 + [ctypes.c_int64] * 3 +
                              [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "dsc_linear_lt_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
+                          [ctypes.c_int, _vp]),
     "dsc_add_layernorm": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_geglu": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
 }

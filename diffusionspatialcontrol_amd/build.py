@@ -39,7 +39,7 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lhipblaslt"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

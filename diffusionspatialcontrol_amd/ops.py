@@ -1,6 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (include/dsc_hip.h).  torch is plumbing here: device memory,
 the current HIP stream and strides; all arithmetic happens in libdsc_hip.so."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -270,6 +271,7 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
     return y
 
 
+USE_LT_RESIDUAL = os.environ.get("DSC_LT_RESIDUAL", "1") != "0"   # GEMMs left to hipBLASLt take bias + residual in the same launch (dsc_linear_lt_f16)
 USE_DSC_GEMM = True        # route qualifying linears to dsc_linear_f16 (False: always hipBLASLt through torch)
 DSC_GEMM_MIN_ROWS = 1024   # measured (tools/mb_gemm.py): the 128x64x64-tile kernel beats hipBLASLt + separate epilogue
 DSC_GEMM_MAX_K = 640       # kernels for >= 1024 token rows and K <= 640; hipBLASLt's larger macro-tiles win beyond
@@ -298,6 +300,17 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
         r2 = residual.reshape(M, N)
         ok = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
     if not ok:
+        if residual is not None and not geglu and USE_LT_RESIDUAL and x.dtype == torch.float16 and K % 8 == 0 and N % 8 == 0:
+            # library GEMM with the bias epilogue AND the residual as beta*C: one launch instead of GEMM + add
+            xl = x.reshape(M, K)
+            rl = residual.reshape(M, N)
+            if (xl.stride(1) == 1 and rl.stride(1) == 1 and xl.stride(0) % 8 == 0 and rl.stride(0) % 8 == 0
+                    and weight.is_contiguous() and weight.dtype == torch.float16):
+                out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+                rc = _lib.load_library().dsc_linear_lt_f16(_p(xl), _p(weight), _p(bias), _p(rl), _p(out), M, N, K,
+                                                           xl.stride(0), rl.stride(0), N, 0, _stream_ptr(x))
+                if rc == 0:
+                    return out.reshape(*lead, N)
         y = torch.nn.functional.linear(x, weight, bias)
         if geglu:
             return globals()["geglu"](y)

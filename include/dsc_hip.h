@@ -238,6 +238,16 @@ int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const v
                          int upsample2x, int splits, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * out = x . w^T (+ bias) (+ residual) as ONE hipBLASLt launch (bias epilogue + beta = 1 with C = residual) - the plain
+ * library GEMM for the token-major linears dsc_linear_f16 does not cover (few rows, long K); replaces `F.linear` + the
+ * separate residual add of diffusers' FeedForward / Transformer2DModel.proj_out / ResnetBlock2D.conv_shortcut.
+ * Same operand conventions as dsc_linear_f16; K, N and the strides multiples of 8.  The first call for a shape queries
+ * the heuristic (and creates the handle / a 32 MiB workspace): run it once outside a graph capture.
+ */
+int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                      int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int dtype, void* stream);
+
+/*
  * (residual add +) LayerNorm over the last dimension - replaces the `x = attn(...) + x` elementwise add and the
  * `nn.LayerNorm` that follows it in diffusers' BasicTransformerBlock (norm1/norm2/norm3, eps 1e-5):
  *   s[r, :]  = x[r, :] + a[r, :]            (a == NULL: s = x)         -> written to `sum_out` when non-NULL (fp16)
