@@ -507,7 +507,10 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
         deps = tuple(p for r in res for p in (r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias))
         W, Bv = _derived(self, "temb", deps, lambda: (torch.cat([r.time_emb_proj.weight for r in res]).contiguous(),
                                                        torch.cat([r.time_emb_proj.bias + r.conv1.bias for r in res])))
-        allp = F.linear(temb_act, W, Bv)
+        if temb_act.is_cuda and temb_act.dtype == torch.float16 and temb_act.shape[0] <= 8:
+            allp = ops.linear_rows(temb_act, W, Bv)
+        else:
+            allp = F.linear(temb_act, W, Bv)
         out, off = {}, 0
         for r in res:
             n = r.time_emb_proj.out_features
@@ -557,8 +560,15 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], dtype=torch.float32, device=sample.device)
         timestep = timestep.reshape(-1).expand(sample.shape[0])
-        emb = self.time_embedding(self.time_proj(timestep, self.cfg.block_out_channels[0]).to(sample.dtype))
-        temb_act = F.silu(emb)                                   # every ResnetBlock applies SiLU to temb first
+        te = self.time_embedding
+        if sample.is_cuda and sample.dtype == torch.float16 and sample.shape[0] <= 8:
+            # Timesteps -> linear_1 -> SiLU -> linear_2 -> SiLU as two few-row GEMV launches (13 kernels before)
+            h1 = ops.linear_rows(timestep.float(), te.linear_1.weight, te.linear_1.bias, silu_out=True,
+                                 sinusoid_dim=self.cfg.block_out_channels[0])
+            temb_act = ops.linear_rows(h1, te.linear_2.weight, te.linear_2.bias, silu_out=True)
+        else:
+            emb = te(self.time_proj(timestep, self.cfg.block_out_channels[0]).to(sample.dtype))
+            temb_act = F.silu(emb)                               # every ResnetBlock applies SiLU to temb first
         if not self._channels_last:                              # conv weights to NHWC once: no per-call transposes
             self.to(memory_format=torch.channels_last)
             # MIOpen has no NHWC implicit-GEMM for 4 channels (it falls back to a 300-400 us naive kernel):

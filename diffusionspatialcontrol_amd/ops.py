@@ -371,6 +371,26 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False):
     return out
 
 
+def linear_rows(x, weight, bias=None, silu_out=False, sinusoid_dim=0):
+    """Few-row linear (<= 8 rows) of the time-embedding path (dsc_linear_rows_f16): act(x @ weight.T + bias).
+    sinusoid_dim > 0: x is an fp32 [M] tensor of timesteps and the input row is its sinusoidal embedding of that width
+    ([cos | sin], diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0)), generated inside the kernel."""
+    _require_gpu(x, weight)
+    N, K = weight.shape
+    if sinusoid_dim:
+        if x.dtype != torch.float32 or x.dim() != 1 or sinusoid_dim != K:
+            raise ValueError("linear_rows: sinusoid input is an fp32 [M] tensor and sinusoid_dim == weight.shape[1]")
+        M, ldx = x.shape[0], 0
+    else:
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        M, ldx = x.shape[0], x.stride(0)
+    out = torch.empty((M, N), dtype=weight.dtype, device=weight.device)
+    flags = (1 if sinusoid_dim else 0) | (2 if silu_out else 0)
+    rc = _lib.load_library().dsc_linear_rows_f16(_p(x), _p(weight), _p(bias), _p(out), M, N, K, ldx, N, flags, 0, _stream_ptr(weight))
+    _lib.check(rc, "dsc_linear_rows_f16")
+    return out
+
+
 def add_bias_residual(a, b, bias=None):
     """a + b + bias[c] over channels-last / token-major fp16 tensors of identical layout (dsc_add_bias_residual)."""
     _require_gpu(a, b)

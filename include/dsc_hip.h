@@ -248,6 +248,17 @@ int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void
                       int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int dtype, void* stream);
 
 /*
+ * Few-row linear (M <= 8) for the time-embedding path: y[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) - `Timesteps` +
+ * `TimestepEmbedding.linear_1/linear_2` (reference u_net_condition_modify.py:554-560, 1040-1060) and the per-ResNet
+ * `time_emb_proj(silu(temb))` projections.  x [M,K] fp16 (row stride ldx) or, with DSC_ROWS_SINUSOID_IN, fp32 t[M] from which
+ * the sinusoidal embedding [cos | sin] of width K is generated on the fly; DSC_ROWS_SILU_OUT applies SiLU to the result.
+ */
+#define DSC_ROWS_SINUSOID_IN 1
+#define DSC_ROWS_SILU_OUT 2
+int dsc_linear_rows_f16(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
+                        int64_t ldx, int64_t ldo, int flags, int dtype, void* stream);
+
+/*
  * (residual add +) LayerNorm over the last dimension - replaces the `x = attn(...) + x` elementwise add and the
  * `nn.LayerNorm` that follows it in diffusers' BasicTransformerBlock (norm1/norm2/norm3, eps 1e-5):
  *   s[r, :]  = x[r, :] + a[r, :]            (a == NULL: s = x)         -> written to `sum_out` when non-NULL (fp16)

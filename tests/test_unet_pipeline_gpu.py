@@ -180,6 +180,33 @@ def test_conv3x3_upsample(ops, B, C, Cout, h, w):
     assert torch.equal(out, ops.conv3x3(up, wt, b))                        # same sums in the same order
 
 
+@pytest.mark.parametrize("M", [1, 2, 5, 8])
+def test_linear_rows_time_embedding(ops, M):
+    """dsc_linear_rows_f16: sinusoidal Timesteps + linear_1 + SiLU, linear_2 + SiLU, the stacked time_emb_proj GEMV"""
+    g = torch.Generator().manual_seed(M)
+    t = (torch.rand(M, generator=g) * 999.0).float()
+    half = 160
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    emb = torch.cat([torch.cos(t[:, None] * freqs[None]), torch.sin(t[:, None] * freqs[None])], dim=-1).half()
+    w1 = (torch.randn(1280, 320, generator=g) / math.sqrt(320)).half()
+    b1 = (torch.randn(1280, generator=g) * 0.1).half()
+    w2 = (torch.randn(1280, 1280, generator=g) / math.sqrt(1280)).half()
+    b2 = (torch.randn(1280, generator=g) * 0.1).half()
+    h_ref = F.silu((emb.float() @ w1.float().t() + b1.float()).half().float()).half()
+    h = ops.linear_rows(t.cuda(), w1.cuda(), b1.cuda(), silu_out=True, sinusoid_dim=320)
+    assert h.shape == (M, 1280)
+    assert torch.all((h.float().cpu() - h_ref.float()).abs() <= 2e-3 * h_ref.float().abs() + 2e-3), (h.float().cpu() - h_ref.float()).abs().max()
+    y_ref = F.silu((h_ref.float() @ w2.float().t() + b2.float()).half().float())
+    y = ops.linear_rows(h_ref.cuda(), w2.cuda(), b2.cuda(), silu_out=True)
+    assert torch.all((y.float().cpu() - y_ref).abs() <= 2e-3 * y_ref.abs() + 2e-3)
+    w3 = (torch.randn(18560 // 8, 1280, generator=g) / math.sqrt(1280)).half()      # a slice of the stacked time_emb_proj
+    z_ref = h_ref.float() @ w3.float().t()
+    big = torch.zeros(M, 1288).half()
+    big[:, :1280] = h_ref
+    z = ops.linear_rows(big.cuda()[:, :1280], w3.cuda())                          # strided rows, no bias, no activation
+    assert torch.all((z.float().cpu() - z_ref).abs() <= 2e-3 * z_ref.abs() + 2e-3)
+
+
 def test_conv3x3_unsupported(ops):
     x = torch.randn(1, 4, 64, 64).half().cuda().contiguous(memory_format=torch.channels_last)
     w = torch.randn(320, 4, 3, 3).half().cuda().contiguous(memory_format=torch.channels_last)
