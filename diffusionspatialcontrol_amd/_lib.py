@@ -65,7 +65,8 @@ _SIGNATURES = {
     "dsc_conv3x3_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "dsc_conv3x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "dsc_conv3x3_nhwc_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 5 + [ctypes.c_int64] * 3 +
-                             [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+                             [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
+    "dsc_conv3x3_fewcin_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 6 + [_vp]),
     "dsc_linear_lt_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                           [ctypes.c_int, _vp]),
     "dsc_linear_rows_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 3 + [ctypes.c_int64] * 2 + [ctypes.c_int, ctypes.c_int, _vp]),

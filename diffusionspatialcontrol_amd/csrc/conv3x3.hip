@@ -40,6 +40,7 @@ struct ConvParams {
     const half_t* x; const half_t* w; const half_t* bias; const half_t* res; half_t* out; float* ws;
     int B, H, W, Cin, Cout;
     int up;                       // 1: x is [B, H/2, W/2, Cin] and is read through a nearest-neighbour 2x upsampling
+    int nchw;                     // 1: out is [B, Cout, H, W] (the UNet's conv_out: 4 channels back to the sampler's layout)
     long long ldx, ldr, ldo;      // pixel strides (elements)
     int nc, splits, cps;          // 64-channel slices, split count, slices per split
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
@@ -299,13 +300,31 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
             *reinterpret_cast<f4x_t*>(dst) = *reinterpret_cast<const f4x_t*>(sp_);
             *reinterpret_cast<f4x_t*>(dst + 4) = *reinterpret_cast<const f4x_t*>(sp_ + 4);
         } else {
-            h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
-            if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + n0 + ch * 8);
-            h8_t o;
+            const int c0 = n0 + ch * 8;
+            if (c0 >= p.Cout) continue;                              // channel padding of a ragged last tile
+            if (c0 + 8 <= p.Cout && !p.nchw) {
+                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + c0);
+                if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + c0);
+                h8_t o;
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)rv[jj]);
-            *reinterpret_cast<h8_t*>(p.out + gp * p.ldo + n0 + ch * 8) = o;
+                for (int jj = 0; jj < 8; ++jj) o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)rv[jj]);
+                *reinterpret_cast<h8_t*>(p.out + gp * p.ldo + c0) = o;
+            } else {
+                // few output channels (conv_out) and / or channel-major output: element-wise
+                const long long hw = (long long)p.H * p.W;
+                const long long pin = gp - (long long)b * hw;        // pixel index inside the image
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int c = c0 + jj;
+                    if (c < p.Cout) {
+                        float v = sp_[jj] + (p.bias ? (float)p.bias[c] : 0.f);
+                        if (p.res) v += (float)p.res[gp * p.ldr + c];
+                        if (p.nchw) p.out[((long long)b * p.Cout + c) * hw + pin] = (half_t)v;
+                        else p.out[gp * p.ldo + c] = (half_t)v;
+                    }
+                }
+            }
         }
     }
     if (p.stamps && threadIdx.x == 0) {
@@ -376,13 +395,14 @@ int auto_splits(int tiles, int nc, long long npix, int cout) {
 
 int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
     const int tw = tile_width(H, W);
-    if (!tw || Cin % BK != 0 || Cout % BN != 0) return 0;
+    if (!tw || Cin % BK != 0 || Cout <= 0) return 0;
     p->B = B; p->H = H; p->W = W; p->Cin = Cin; p->Cout = Cout;
     p->nc = Cin / BK;
     p->bpr = W / tw; p->bpi = (H / 8) * p->bpr; p->nblk = B * p->bpi;
     const int nsb = 16 / tw;
-    p->mt = (p->nblk + nsb - 1) / nsb; p->nt = Cout / BN;
+    p->mt = (p->nblk + nsb - 1) / nsb; p->nt = (Cout + BN - 1) / BN;    // a ragged last tile reads zero weight rows (buffer bounds)
     p->npix = (long long)B * H * W;
+    if (Cout % BN != 0) splits = 1;                                      // the partial-sum layout assumes whole tiles
     if (splits <= 0) splits = auto_splits(p->mt * p->nt, p->nc, p->npix, Cout);
     if (splits > p->nc) splits = p->nc;
     p->cps = (p->nc + splits - 1) / splits;
@@ -409,12 +429,12 @@ extern "C" size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int 
 
 extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                     int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
-                                    int upsample2x, int splits, int dtype, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+                                    int upsample2x, int out_nchw, int splits, int dtype, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
-    if (ldx < Cin || ldo < Cout || (residual && ldr < Cout)) return DSC_ERR_BAD_ARG;
-    if (ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;
+    if (ldx < Cin || (!out_nchw && ldo < Cout) || (residual && ldr < Cout)) return DSC_ERR_BAD_ARG;
+    if (ldx % 8 != 0 || (Cout % 8 == 0 && !out_nchw && ldo % 8 != 0) || (residual && Cout % 8 == 0 && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(w) || !al16(out) || (bias && !al16(bias)) || (residual && !al16(residual))) return DSC_ERR_UNSUPPORTED;
     // 32-bit byte offsets in the buffer-addressed DMAs (and kOob must lie beyond every extent)
     if ((long long)B * H * W * (ldx > ldo ? ldx : ldo) >= (1ll << 30) || 9ll * Cin * Cout >= (1ll << 30)) return DSC_ERR_UNSUPPORTED;
@@ -427,6 +447,7 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.stamps = g_conv_stamps;
     p.up = upsample2x ? 1 : 0;
+    p.nchw = out_nchw ? 1 : 0;
     {
         const long long in_pix = upsample2x ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
         p.x_bytes = (unsigned)(((in_pix - 1) * ldx + Cin) * 2);

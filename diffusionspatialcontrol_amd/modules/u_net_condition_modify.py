@@ -582,7 +582,13 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
                 raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
                                  "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
             encoder_hidden_states = (encoder_hidden_states, self.encoder_hid_proj(added_cond_kwargs.get("image_embeds")))
-        x = self.conv_in(sample.contiguous()).contiguous(memory_format=torch.channels_last)
+        ci = self.conv_in
+        if (sample.is_cuda and sample.dtype == torch.float16 and ci.in_channels <= 8 and ci.out_channels % 8 == 0
+                and ci.out_channels <= 512 and sample.shape[-1] % 8 == 0 and ops.USE_DSC_CONV):
+            wt = _derived(self, "conv_in_t", (ci.weight,), lambda: ci.weight.reshape(ci.out_channels, -1).t().contiguous())
+            x = ops.conv3x3_fewcin(sample, wt, ci.bias, ci.out_channels)     # NCHW latents -> NHWC features, one launch
+        else:
+            x = ci(sample.contiguous()).contiguous(memory_format=torch.channels_last)
         tadd = self._all_temb_adds(temb_act)
         skips = [x]
         for blk in self.down_blocks:
@@ -609,5 +615,11 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
                     x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
             if hasattr(blk, "upsamplers"):
                 x = blk.upsamplers[0](x)
-        x = self.conv_out(self.conv_norm_out(x).contiguous()).contiguous()   # reference :1304-1307; NCHW out
+        h = self.conv_norm_out(x)                                            # reference :1304-1307
+        co = self.conv_out
+        wcl = _derived(self, "conv_out_cl", (co.weight,), lambda: co.weight.contiguous(memory_format=torch.channels_last))
+        if ops.conv3x3_supported(h, wcl):
+            x = ops.conv3x3(h, wcl, co.bias, out_nchw=True)                   # the sampler's layout, no conversion pass
+        else:
+            x = co(h.contiguous()).contiguous()
         return UNet2DConditionOutput(sample=x) if return_dict else (x,)

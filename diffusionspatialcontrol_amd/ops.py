@@ -338,11 +338,12 @@ def conv3x3_supported(x, weight, upsample=False):
     return bool(_lib.load_library().dsc_conv3x3_supported(B, H * f, W * f, C, weight.shape[0]))
 
 
-def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False):
+def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_nchw=False):
     """3x3 / stride 1 / pad 1 convolution (+ bias) (+ residual) of a channels_last fp16 [B, Cin, H, W] tensor with a
     [Cout, Cin, 3, 3] weight held in channels_last memory format (dsc_conv3x3_nhwc_f16); returns channels_last
-    [B, Cout, H, W].  upsample=True convolves the 2x nearest-neighbour upsampling of x (output [B, Cout, 2H, 2W]) without
-    materialising it.  Raises on an unsupported shape - ask conv3x3_supported() first."""
+    [B, Cout, H, W], or a plain contiguous (NCHW) tensor with out_nchw=True.  upsample=True convolves the 2x
+    nearest-neighbour upsampling of x (output [B, Cout, 2H, 2W]) without materialising it.  Raises on an unsupported
+    shape - ask conv3x3_supported() first."""
     _require_gpu(x, weight)
     lib = _lib.load_library()
     cl = torch.channels_last
@@ -354,7 +355,10 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False):
     if upsample:
         H, W = 2 * H, 2 * W
     Cout = weight.shape[0]
-    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+    if out_nchw:
+        out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+    else:
+        out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
     ldr = 0
     if residual is not None:
         if residual.shape != out.shape:
@@ -365,9 +369,21 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False):
     nbytes = lib.dsc_conv3x3_workspace_bytes(B, H, W, Cin, Cout, splits)
     ws = _workspace(x.device, nbytes) if nbytes else None
     rc = lib.dsc_conv3x3_nhwc_f16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, Cin, ldr, Cout,
-                                  1 if upsample else 0, splits, 0, _p(ws), ws.numel() * 8 if ws is not None else 0,
-                                  _stream_ptr(x))
+                                  1 if upsample else 0, 1 if out_nchw else 0, splits, 0, _p(ws),
+                                  ws.numel() * 8 if ws is not None else 0, _stream_ptr(x))
     _lib.check(rc, "dsc_conv3x3_nhwc_f16")
+    return out
+
+
+def conv3x3_fewcin(x, weight_t, bias, cout):
+    """3x3 / pad 1 convolution of a plain (NCHW) fp16 [B, Cin <= 8, H, W] tensor -> channels_last [B, cout, H, W]
+    (dsc_conv3x3_fewcin_f16); weight_t is weight.reshape(cout, Cin * 9).t().contiguous()."""
+    _require_gpu(x, weight_t)
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    out = torch.empty((B, cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = _lib.load_library().dsc_conv3x3_fewcin_f16(_p(x), _p(weight_t), _p(bias), _p(out), B, Cin, H, W, cout, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_conv3x3_fewcin_f16")
     return out
 
 

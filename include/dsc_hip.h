@@ -223,9 +223,11 @@ int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* r
  * format), residual / out [B,H,W,Cout] with pixel strides ldr / ldo.  fp32 accumulation, one fp16 rounding.
  * upsample2x != 0: x is [B,H/2,W/2,Cin] and the convolution reads it through a nearest-neighbour 2x upsampling
  * (diffusers Upsample2D = F.interpolate(scale_factor=2, mode="nearest") + conv) without materialising the upsampled image.
+ * out_nchw != 0: out is [B,Cout,H,W] (channel-major; the UNet's 4-channel conv_out hands its result back in the sampler's
+ * layout).  Cout need not be a multiple of 64: a ragged last channel tile reads zero weight rows through the buffer bounds.
  * splits: number of input-channel ranges accumulated by separate workgroups (0 = chosen from the shape); splits > 1
  * needs `workspace` (dsc_conv3x3_workspace_bytes) and sums the partials in range order: bit-reproducible.
- * Supported (dsc_conv3x3_supported): Cin % 64 == 0, Cout % 64 == 0, H % 8 == 0, W % 8 == 0, strides % 8 == 0, 16-byte
+ * Supported (dsc_conv3x3_supported): Cin % 64 == 0, H % 8 == 0, W % 8 == 0, strides % 8 == 0 (when Cout % 8 == 0), 16-byte
  * aligned pointers; anything else returns DSC_ERR_UNSUPPORTED and the caller keeps the library convolution.
  */
 int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
@@ -235,7 +237,17 @@ void dsc_debug_set_conv_stamps(void* device_buffer);
 size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
 int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                          int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
-                         int upsample2x, int splits, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+                         int upsample2x, int out_nchw, int splits, int dtype, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/*
+ * 3x3 / pad 1 convolution with few input channels (<= 8) - the UNet's `conv_in` (4 -> 320; reference
+ * u_net_condition_modify.py:352-356,1187): x [B,Cin,H,W] channel-major fp16 (the sampler's latent layout),
+ * w_t [9*Cin, Cout] = weight.reshape(Cout, Cin*9).t() (k = (ci*3 + dy)*3 + dx), out [B,H,W,Cout] channels-last, bias fused.
+ * Cout % 8 == 0, Cout <= 512, W % 8 == 0.
+ */
+int dsc_conv3x3_fewcin_f16(const void* x_nchw, const void* w_t, const void* bias, void* out_nhwc,
+                           int B, int Cin, int H, int W, int Cout, int dtype, void* stream);
 
 /*
  * out = x . w^T (+ bias) (+ residual) as ONE hipBLASLt launch (bias epilogue + beta = 1 with C = residual) - the plain

@@ -207,10 +207,47 @@ def test_linear_rows_time_embedding(ops, M):
     assert torch.all((z.float().cpu() - z_ref).abs() <= 2e-3 * z_ref.abs() + 2e-3)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,nchw", [(2, 320, 4, 64, 64, True), (1, 64, 4, 8, 8, True), (2, 128, 40, 16, 16, False),
+                                                 (1, 64, 100, 8, 16, False), (2, 64, 72, 8, 8, True)])
+def test_conv3x3_ragged_cout_and_nchw(ops, B, Cin, Cout, H, W, nchw):
+    """conv_out (320 -> 4, channel-major result) and other channel counts that are not multiples of 64: the ragged
+    channel tile reads zero weight rows through the buffer bounds"""
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    cl = torch.channels_last
+    x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=cl)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half().cuda().contiguous(memory_format=cl)
+    b = (torch.randn(Cout, generator=g) * 0.2).half().cuda()
+    assert ops.conv3x3_supported(x, w)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    out = ops.conv3x3(x, w, b, out_nchw=nchw)
+    assert out.shape == ref.shape and (out.is_contiguous() if nchw else out.is_contiguous(memory_format=cl))
+    assert torch.all((out.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3), (out.float() - ref).abs().max().item()
+    assert torch.equal(out, ops.conv3x3(x, w, b, out_nchw=nchw))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 4, 320, 64, 64), (1, 4, 320, 96, 96), (3, 8, 64, 8, 16), (1, 3, 128, 16, 8)])
+def test_conv3x3_fewcin(ops, B, Cin, Cout, H, W):
+    """conv_in: channel-major latents -> channels-last features, bias fused, zero padding at the borders"""
+    g = torch.Generator().manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).half().cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half().cuda()
+    b = (torch.randn(Cout, generator=g) * 0.2).half().cuda()
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    out = ops.conv3x3_fewcin(x, w.reshape(Cout, -1).t().contiguous(), b, Cout)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.all((out.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3), (out.float() - ref).abs().max().item()
+    xi = torch.zeros(B, Cin, H, W).half()
+    xi[B - 1, Cin - 1, H - 1, 0] = 1.0
+    xi[0, 0, 0, W - 1] = -2.0
+    oi = ops.conv3x3_fewcin(xi.cuda(), w.reshape(Cout, -1).t().contiguous(), None, Cout).float().cpu()
+    ri = F.conv2d(xi.float(), w.float().cpu(), None, padding=1)
+    assert torch.all((oi - ri).abs() <= 1e-3 * ri.abs() + 1e-6)
+
+
 def test_conv3x3_unsupported(ops):
     x = torch.randn(1, 4, 64, 64).half().cuda().contiguous(memory_format=torch.channels_last)
     w = torch.randn(320, 4, 3, 3).half().cuda().contiguous(memory_format=torch.channels_last)
-    assert not ops.conv3x3_supported(x, w)
+    assert not ops.conv3x3_supported(x, w)                                # Cin must be a multiple of 64
     with pytest.raises(Exception):
         ops.conv3x3(x, w)
     x2 = torch.randn(1, 64, 12, 12).half().cuda().contiguous(memory_format=torch.channels_last)
