@@ -57,7 +57,7 @@ __device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, c
 
 // ------------------------------------------------------------------------------------------ phase 1
 template <int NK, bool REF16>
-__global__ __launch_bounds__(kThreads) void xattn_stats(XattnParams p) {
+__global__ __launch_bounds__(kThreads, 2) void xattn_stats(XattnParams p) {   // 2 waves per SIMD: score accumulators stay in VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KP = XCfg<NK>::KP;
     half_t* Ks = reinterpret_cast<half_t*>(smem);

@@ -97,7 +97,7 @@ __device__ __forceinline__ void scores_img(const XattnParams& p, const half_t* i
 
 // ---------------------------------------------------------------------------------------------- statistics
 template <int NK, bool REF16>
-__global__ __launch_bounds__(kThreads) void xp_stats(XpParams pp) {
+__global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 waves per SIMD: score accumulators stay in VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using P = PCfg<NK>;
     const XattnParams& p = pp.x;

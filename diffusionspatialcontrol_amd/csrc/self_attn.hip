@@ -51,6 +51,14 @@ __device__ __forceinline__ void hidden_load(h8_t& dst, const half_t* src) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
 }
 
+// one v_max3_f32; fmaxf() costs a canonicalising v_max_f32 per input on top of the max itself (53 + 8 instructions per
+// tile instead of 16) and the kernel is VALU-issue bound.  Scores are finite or -inf, never NaN.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ h4_t tr_read(const half_t* p) {
     const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (s4_t __attribute__((address_space(3)))*)(const_cast<half_t*>(p)));
@@ -72,8 +80,11 @@ unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cyc
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
 
+// Head dims <= 80: ask for two waves per SIMD (256 registers per wave).  Without the second launch-bound the compiler
+// parks the S / O accumulators in AGPRs and moves them to VGPRs and back for the softmax and the rescale:
+// 191 of the 277 VALU instructions per tile were v_accvgpr_read/write (rocprofv3 PMC: the kernel is VALU-issue bound).
 template <int NK, int WAVES, int QT>
-__global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
+__global__ __launch_bounds__(64 * WAVES, (NK <= 5 && QT == 1 && WAVES >= 2 ? 2 : 1)) void self_attn_fwd(SaParams p) {   // HIP: 2nd = min waves per SIMD
     using C = SaCfg<NK>;
     constexpr int T = 64 * WAVES, DM = C::DM, KP = C::KP, VP = C::VP;
     constexpr int CH = (kKV * 2 * NK + T - 1) / T;          // 16-byte chunks per thread per operand per tile
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(64 * WAVES) void self_attn_fwd(SaParams p) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int i = 0; i < 16; i += 2) mx = fmaxf(mx, fmaxf(s[qt][m][i], s[qt][m][i + 1]));   // v_max3_f32
+                for (int i = 0; i < 16; i += 2) mx = max3(mx, s[qt][m][i], s[qt][m][i + 1]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;     // c2 > 0: max commutes with the scaling
             if (__any(mx > m_run[qt] + kTau)) {              // wave-uniform: some row's max grew by more than 2^tau
                 const float m_new = fmaxf(m_run[qt], mx);
