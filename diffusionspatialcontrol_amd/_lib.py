@@ -62,6 +62,7 @@ _SIGNATURES = {
     "dsc_linear_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                        [ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_debug_set_conv_stamps": (None, [_vp]),
+    "dsc_debug_set_conv_ring": (None, [ctypes.c_int]),
     "dsc_conv3x3_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "dsc_conv3x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "dsc_conv3x3_nhwc_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 5 + [ctypes.c_int64] * 3 +

@@ -27,12 +27,16 @@ namespace {
 
 constexpr int BM = 128, BN = 64, BK = 64, T = 256;
 constexpr int kBStageBytes = BN * BK * 2;        // one weight tile: 8 KiB
-constexpr int kStages = 3;                       // ring depth; 9 taps % 3 == 0 makes a tile's stage its tap % 3: compile-time
+// Ring depth S: 9 taps % S == 0 makes a weight tile's stage its tap % S - compile-time.  S = 3 (75 KiB, two workgroups per
+// CU) is what runs; S = 9 (123 KiB, one per CU, eight tiles in flight) is kept as a diagnostic variant
+// (dsc_debug_set_conv_ring): it is slower on every shape, i.e. the step is not waiting for DMA latency.
 constexpr int kAPiecesMax = 25;                  // 200 halo slots
 constexpr int kABytes = kAPiecesMax * 1024;      // one halo buffer: 25 KiB
 // LDS map (bytes): weight ring | halo buffer 0 | halo buffer 1 | landing pad for the DMA pieces beyond the halo
-constexpr int kRingOff = 0, kAOff = kStages * kBStageBytes, kPadOff = kAOff + 2 * kABytes;
-constexpr int kLdsBytes = kPadOff + 1024;        // 76800 B -> two workgroups per CU
+constexpr int kRingOff = 0;
+constexpr int a_off(int S) { return S * kBStageBytes; }
+constexpr int pad_off(int S) { return a_off(S) + 2 * kABytes; }
+constexpr int lds_bytes(int S) { return pad_off(S) + 1024; }   // S = 3: 76800 B
 constexpr int kEpiStride = BN + 4;
 constexpr unsigned kOob = 0x80000000u;           // buffer offset beyond any supported tensor: the load returns zeros
 
@@ -64,11 +68,28 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("" ::: "memory");
 }
 
-// DMA instructions a wave issues after weight tile j+1 (the last thing step j-2 issued) up to step j-1, for step j at
-// tap t: step j-1 only - 9 when that was a tap-0 step (7 halo pieces + 2 weight pieces), else 2
+// DMA instructions a wave issues after weight tile j+1 (the last thing step j+1-S issued) up to step j-1, for step j at
+// tap t: steps j-1 .. j-(S-2), 9 for a tap-0 step (7 halo pieces + 2 weight pieces), else 2.  The next slice's halo is
+// issued first in the tap-0 step, i.e. before the tile the tap-8 step waits for (S <= 9): no extra condition.
+template <int S>
+constexpr int younger_dmas(int t) {
+    int n = 0;
+    for (int i = 1; i <= S - 2; ++i) n += ((t - i) % 9 + 9) % 9 == 0 ? 9 : 2;
+    return n;
+}
+template <int S>
 __device__ __forceinline__ void wait_step(int t) {
-    if (t == 1) wait_vm<9>();                                     // t is a compile-time constant after unrolling
-    else wait_vm<2>();
+    switch (t) {                                                  // t is a compile-time constant after unrolling
+        case 0: wait_vm<younger_dmas<S>(0)>(); break;
+        case 1: wait_vm<younger_dmas<S>(1)>(); break;
+        case 2: wait_vm<younger_dmas<S>(2)>(); break;
+        case 3: wait_vm<younger_dmas<S>(3)>(); break;
+        case 4: wait_vm<younger_dmas<S>(4)>(); break;
+        case 5: wait_vm<younger_dmas<S>(5)>(); break;
+        case 6: wait_vm<younger_dmas<S>(6)>(); break;
+        case 7: wait_vm<younger_dmas<S>(7)>(); break;
+        default: wait_vm<younger_dmas<S>(8)>(); break;
+    }
 }
 
 // bank-conflict swizzle of a halo slot's 16-byte chunks: ds_read_b128 serves lanes in groups of 16 over 64 banks, a
@@ -86,8 +107,10 @@ __device__ __forceinline__ h8_t lds_read(unsigned byte_addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) h8_t*>((uintptr_t)byte_addr);
 }
 
-template <int TW>
-__global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
+template <int TW, int S>
+__global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams p) {
+    static_assert(S == 3 || S == 9, "the ring depth must divide the 9 taps");
+    constexpr int kAOff = a_off(S), kPadOff = pad_off(S);
     constexpr int NSB = 16 / TW;                 // sub-blocks of 8 x TW pixels per tile
     constexpr int HWD = TW + 2;                  // halo row width (even)
     constexpr int HS = 10 * HWD;                 // halo slots per sub-block
@@ -136,10 +159,9 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
     };
     auto tile_soff = [&](int c, int t) { return ((unsigned)t * (unsigned)p.Cin + (unsigned)c * BK) * 2u; };
 
-    // the weight tiles of steps 0..2 go out first: their latency overlaps the halo index arithmetic below
-    issue_b(tile_soff(cb, 0), 0);
-    issue_b(tile_soff(cb, 1), 1);            // ns >= 9
-    issue_b(tile_soff(cb, 2), 2);
+    // the weight tiles of steps 0..S-1 go out first: their latency overlaps the halo index arithmetic below
+#pragma unroll
+    for (int k = 0; k < S; ++k) issue_b(tile_soff(cb, k), k);      // ns >= 9 >= S
 
     // ---- sub-block origins (wave-uniform: at most two per tile, so the runtime divisions run once, not per lane)
     int ob[NSB], oy[NSB], ox[NSB];
@@ -178,7 +200,7 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
     // ---- MFMA operand addresses (bytes).  Fragment 0 of this wave covers pixels wm*64 + r, fragment 1 the 32 pixels
     // after them: the same halo column, 2 (TW = 16) or 4 (TW = 8) halo rows below -> a constant byte distance.
     // xaddr[par][dx][ks]: top-left tap (dy = dx = -1) slot + dx, chunk (2 ks + hh) ^ swizzle; a tap adds dy * pitch.
-    unsigned xaddr[NPAR][3][4], waddr[4];
+    unsigned xaddr[NPAR][3][4], waddr[4], waddr_hi[4];
     {
         const int m = wm * 64 + r;
         const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
@@ -189,20 +211,23 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
             for (int dx = 0; dx < 3; ++dx) {
                 const int sw = halo_swz<TW>(py + par, pxl + dx);   // par = parity offset of the tap row (dy index & 1)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) xaddr[par][dx][ks] = (unsigned)((slot00 + dx) * 128 + (((2 * ks + hh) ^ sw) << 4));
+                for (int ks = 0; ks < 4; ++ks) xaddr[par][dx][ks] = (unsigned)(kAOff + (slot00 + dx) * 128 + (((2 * ks + hh) ^ sw) << 4));
             }
         const int wrow = wn * 32 + r;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) waddr[ks] = (unsigned)(wrow * 128 + (((2 * ks + hh) ^ ((wrow >> 1) & 7)) << 4));
+        for (int ks = 0; ks < 4; ++ks) {
+            waddr[ks] = (unsigned)(kRingOff + wrow * 128 + (((2 * ks + hh) ^ ((wrow >> 1) & 7)) << 4));
+            waddr_hi[ks] = waddr[ks] + 4 * kBStageBytes;        // stages 4..8 of the deep ring
+        }
     }
     // fragments of step (halo buffer ab, tap t, ring stage t % 3)
     auto load_frags = [&](Frags& f, int ab, int t) {
         const int dy = t / 3, dx = t % 3;
-        const unsigned abase = kAOff + ab * kABytes + dy * HWD * 128;
-        const unsigned bbase = kRingOff + (t % 3) * kBStageBytes;
+        const unsigned abase = ab * kABytes + dy * HWD * 128;          // kAOff is folded into xaddr (16-bit ds_read immediates)
+        const int stg = t % S;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            f.w[ks] = lds_read(waddr[ks] + bbase);
+            f.w[ks] = stg < 4 ? lds_read(waddr[ks] + stg * kBStageBytes) : lds_read(waddr_hi[ks] + (stg - 4) * kBStageBytes);
             f.x0[ks] = lds_read(xaddr[NPAR == 1 ? 0 : (dy & 1)][dx][ks] + abase);
             f.x1[ks] = lds_read(xaddr[NPAR == 1 ? 0 : (dy & 1)][dx][ks] + abase + MT1);
         }
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
     if (p.stamps) { st1 = __builtin_amdgcn_s_memrealtime(); sc1 = __builtin_amdgcn_s_memtime(); }
 
     // ---- main loop.  Step j = (slice c, tap t).  The barrier of step j publishes weight tile j+1 (and, at t = 8, the
-    // next slice's halo), proves every wave holds tile j in registers (so its ring stage is refilled with tile j+3), and
+    // next slice's halo), proves every wave holds tile j in registers (so its ring stage is refilled with tile j+S), and
     // the fragments of step j+1 are read while step j's MFMAs run.  A step has no branch: past the last tile / slice the
     // DMAs re-fetch a valid tile into a stage nobody reads again, and the last fragment read is discarded.
     // Every step issues 2 weight pieces (+ the next slice's 7 halo pieces at tap 0) per wave: compile-time vmcnt.
@@ -236,7 +261,7 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
         for (int t = 0; t < 9; ++t) {
             Frags& cur = f[(P + t) & 1];
             Frags& nxt = f[(P + t + 1) & 1];
-            wait_step(t);
+            wait_step<S>(t);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // step j's fragments are in registers
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);                       // keep step j+1's MFMAs out of step j (they would wait on their reads)
@@ -245,9 +270,9 @@ __global__ __launch_bounds__(T, 2) void conv3x3_kernel(ConvParams p) {
                 for (int i = 0; i < 7; ++i) issue_a(i, cn, P ^ 1);
             }
             {
-                const bool more = jb + t + 3 < ns;
-                const int c3 = t + 3 >= 9 ? c + 1 : c, t3 = (t + 3) % 9;
-                issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % 3);
+                const bool more = jb + t + S < ns;
+                const int c3 = t + S >= 9 ? c + 1 : c, t3 = (t + S) % 9;
+                issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % S);
             }
             if (t < 8) load_frags(nxt, P, t + 1);
             else load_frags(nxt, P ^ 1, 0);
@@ -362,6 +387,7 @@ __global__ __launch_bounds__(256) void conv3x3_reduce(ConvParams p) {
 }
 
 long long* g_conv_stamps = nullptr;
+int g_conv_ring = 0;          // diagnostics (dsc_debug_set_conv_ring): 0 = from the grid size, 3 or 9 = forced
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -414,6 +440,8 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
+extern "C" void dsc_debug_set_conv_ring(int stages) { g_conv_ring = stages; }
+
 extern "C" int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
     ConvParams p{};
     if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W * (long long)(Cin > Cout ? Cin : Cout) >= (1ll << 30) ||
@@ -460,14 +488,24 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fns[] = {reinterpret_cast<const void*>(&conv3x3_kernel<16, 3>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 3>),
+                             reinterpret_cast<const void*>(&conv3x3_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9>)};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int total = p.mt * p.nt * p.splits;
     const dim3 grid(((total + 7) / 8) * 8), block(T);
-    if (tw == 16) hipLaunchKernelGGL((conv3x3_kernel<16>), grid, block, (size_t)kLdsBytes, st, p);
-    else hipLaunchKernelGGL((conv3x3_kernel<8>), grid, block, (size_t)kLdsBytes, st, p);
+    // 3 stages unless forced: the 9-stage ring (one workgroup per CU) measured slower on every UNet shape
+    // (tools/mb_conv3.py: 320->320 @64x64 23.6 us vs 31.4 us) - a step does not wait for the DMA latency
+    int ring = g_conv_ring;
+    if (ring != 3 && ring != 9) ring = 3;
+    if (tw == 16) {
+        if (ring == 9) hipLaunchKernelGGL((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
+        else hipLaunchKernelGGL((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);
+    } else {
+        if (ring == 9) hipLaunchKernelGGL((conv3x3_kernel<8, 9>), grid, block, (size_t)lds_bytes(9), st, p);
+        else hipLaunchKernelGGL((conv3x3_kernel<8, 3>), grid, block, (size_t)lds_bytes(3), st, p);
+    }
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     if (p.splits > 1) {
         const long long n = p.npix * (Cout / 8);

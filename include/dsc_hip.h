@@ -234,6 +234,8 @@ int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
 /* diagnostics: 8 x int64 per workgroup (start / loop start / loop end / end in 100 MHz ticks, the three segment lengths in
  * shader clocks, XCC and HW ids) of every following dsc_conv3x3_nhwc_f16 call go to `device_buffer`; NULL switches it off */
 void dsc_debug_set_conv_stamps(void* device_buffer);
+/* diagnostics: force the weight-tile ring depth (3 or 9 stages); 0 = chosen from the grid size */
+void dsc_debug_set_conv_ring(int stages);
 size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
 int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                          int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,

@@ -30,9 +30,14 @@ for (B, cin, cout, hw) in shapes:
     t0 = tm_graph(lambda: F.conv2d(x, w, None, padding=1))
     line = f"conv3x3 B{B} {cin:4d}->{cout:4d} @{hw:2d}: miopen {t0:7.1f} us ({fl/t0/1e6:4.0f} TF) | dsc"
     nc = cin // 64
-    for s in [0] + [s for s in (1, 2, 5, 10, 20) if s <= nc and nc % s == 0]:
+    for s in [0]:
         t = tm_graph(lambda: ops.conv3x3(x, w, None, splits=s))
         line += f" s{s}:{t:6.1f}({fl/t/1e6:4.0f})"
+    for ring in (3, 9):
+        lib.dsc_debug_set_conv_ring(ring)
+        t = tm_graph(lambda: ops.conv3x3(x, w, None))
+        line += f" r{ring}:{t:6.1f}"
+    lib.dsc_debug_set_conv_ring(0)
     ref = F.conv2d(x, w, None, padding=1)
     err = (ops.conv3x3(x, w, None) - ref).abs().max().item()
     print(line + f" | maxdiff {err:.2e}", flush=True)
