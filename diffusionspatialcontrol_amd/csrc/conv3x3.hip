@@ -45,6 +45,8 @@ struct ConvParams {
     int B, H, W, Cin, Cout;
     int up;                       // 1: x is [B, H/2, W/2, Cin] and is read through a nearest-neighbour 2x upsampling
     int nchw;                     // 1: out is [B, Cout, H, W] (the UNet's conv_out: 4 channels back to the sampler's layout)
+    int sub2;                     // 1: only the even pixels are kept: out is [B, H/2, W/2, Cout] = the stride-2 convolution
+    long long onpix;              // output pixels (npix, or npix / 4 with sub2)
     long long ldx, ldr, ldo;      // pixel strides (elements)
     int nc, splits, cps;          // 64-channel slices, split count, slices per split
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
@@ -317,11 +319,15 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
         const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;      // sb = cidx / 2 for TW = 8: uniform
         const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
         if (b < 0) continue;
-        const long long gp = ((long long)b * p.H + (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py) * p.W +
-                             (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
+        const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
+        long long gp = ((long long)b * p.H + yy) * p.W + xx;
+        if (p.sub2) {                                                // stride 2 = the even pixels of the stride-1 result
+            if ((yy | xx) & 1) continue;
+            gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1);
+        }
         const float* sp_ = stage + m * kEpiStride + ch * 8;
         if (p.splits > 1) {
-            float* dst = p.ws + ((long long)sp * p.npix + gp) * p.Cout + n0 + ch * 8;
+            float* dst = p.ws + ((long long)sp * p.onpix + gp) * p.Cout + n0 + ch * 8;
             *reinterpret_cast<f4x_t*>(dst) = *reinterpret_cast<const f4x_t*>(sp_);
             *reinterpret_cast<f4x_t*>(dst + 4) = *reinterpret_cast<const f4x_t*>(sp_ + 4);
         } else {
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
                 *reinterpret_cast<h8_t*>(p.out + gp * p.ldo + c0) = o;
             } else {
                 // few output channels (conv_out) and / or channel-major output: element-wise
-                const long long hw = (long long)p.H * p.W;
+                const long long hw = p.onpix / p.B;
                 const long long pin = gp - (long long)b * hw;        // pixel index inside the image
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -367,12 +373,12 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
 __global__ __launch_bounds__(256) void conv3x3_reduce(ConvParams p) {
     const int cv = p.Cout / 8;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.npix * cv) return;
+    if (idx >= p.onpix * cv) return;
     const long long gp = idx / cv;
     const int n = (int)(idx % cv) * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < p.splits; ++k) {
-        const float* src = p.ws + ((long long)k * p.npix + gp) * p.Cout + n;
+        const float* src = p.ws + ((long long)k * p.onpix + gp) * p.Cout + n;
         const f4x_t a = *reinterpret_cast<const f4x_t*>(src), b = *reinterpret_cast<const f4x_t*>(src + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s[j] += a[j]; s[4 + j] += b[j]; }
@@ -457,7 +463,7 @@ extern "C" size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int 
 
 extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                     int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
-                                    int upsample2x, int out_nchw, int splits, int dtype, void* workspace,
+                                    int resample, int out_nchw, int splits, int dtype, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
@@ -474,15 +480,18 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     p.out = static_cast<half_t*>(out); p.ws = static_cast<float*>(workspace);
     p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.stamps = g_conv_stamps;
-    p.up = upsample2x ? 1 : 0;
+    if (resample < 0 || resample > 2 || (resample == DSC_CONV_STRIDE2 && out_nchw)) return DSC_ERR_UNSUPPORTED;
+    p.up = resample == DSC_CONV_UPSAMPLE2X ? 1 : 0;
+    p.sub2 = resample == DSC_CONV_STRIDE2 ? 1 : 0;
+    p.onpix = p.sub2 ? p.npix / 4 : p.npix;
     p.nchw = out_nchw ? 1 : 0;
     {
-        const long long in_pix = upsample2x ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
+        const long long in_pix = p.up ? (long long)B * (H / 2) * (W / 2) : (long long)B * H * W;
         p.x_bytes = (unsigned)(((in_pix - 1) * ldx + Cin) * 2);
         p.w_bytes = (unsigned)(9ll * Cin * Cout * 2);
     }
     if (p.splits > 1) {
-        const size_t need = (size_t)p.splits * p.npix * Cout * sizeof(float);
+        const size_t need = (size_t)p.splits * p.onpix * Cout * sizeof(float);
         if (!workspace || workspace_bytes < need || !al16(workspace)) return DSC_ERR_WORKSPACE;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -508,7 +517,7 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     }
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     if (p.splits > 1) {
-        const long long n = p.npix * (Cout / 8);
+        const long long n = p.onpix * (Cout / 8);
         hipLaunchKernelGGL(conv3x3_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     }

@@ -393,6 +393,8 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, stride=2, padding=1)
 
     def forward(self, x):
+        if x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0 and ops.conv3x3_supported(x, self.conv.weight):
+            return ops.conv3x3(x, self.conv.weight, self.conv.bias, stride2=True)      # even pixels of the stride-1 taps
         return self.conv(x)
 
 

@@ -221,8 +221,11 @@ int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* r
  *   out[b,y,x,n] = sum_{dy,dx,c} x[b,y+dy-1,x+dx-1,c] * w[n,dy,dx,c]  (+ bias[n]) (+ residual[b,y,x,n]),  zero padding
  * x [B,H,W,Cin] with pixel stride ldx, w [Cout,3,3,Cin] contiguous (a torch conv weight in channels_last memory
  * format), residual / out [B,H,W,Cout] with pixel strides ldr / ldo.  fp32 accumulation, one fp16 rounding.
- * upsample2x != 0: x is [B,H/2,W/2,Cin] and the convolution reads it through a nearest-neighbour 2x upsampling
- * (diffusers Upsample2D = F.interpolate(scale_factor=2, mode="nearest") + conv) without materialising the upsampled image.
+ * resample == DSC_CONV_UPSAMPLE2X: x is [B,H/2,W/2,Cin] and the convolution reads it through a nearest-neighbour 2x
+ * upsampling (diffusers Upsample2D = F.interpolate(scale_factor=2, mode="nearest") + conv) without materialising the image.
+ * resample == DSC_CONV_STRIDE2: only the even pixels are stored, out is [B,H/2,W/2,Cout] - the stride-2 / pad-1 convolution of
+ * diffusers Downsample2D (3 per UNet step).  The taps still run at H x W (4x the necessary MFMA work); it is nevertheless
+ * faster than MIOpen's stride-2 kernels here (24-27 us vs 31-37 us) and, unlike their atomic split-K, bit-reproducible.
  * out_nchw != 0: out is [B,Cout,H,W] (channel-major; the UNet's 4-channel conv_out hands its result back in the sampler's
  * layout).  Cout need not be a multiple of 64: a ragged last channel tile reads zero weight rows through the buffer bounds.
  * splits: number of input-channel ranges accumulated by separate workgroups (0 = chosen from the shape); splits > 1
@@ -230,6 +233,8 @@ int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* r
  * Supported (dsc_conv3x3_supported): Cin % 64 == 0, H % 8 == 0, W % 8 == 0, strides % 8 == 0 (when Cout % 8 == 0), 16-byte
  * aligned pointers; anything else returns DSC_ERR_UNSUPPORTED and the caller keeps the library convolution.
  */
+#define DSC_CONV_UPSAMPLE2X 1
+#define DSC_CONV_STRIDE2 2
 int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
 /* diagnostics: 8 x int64 per workgroup (start / loop start / loop end / end in 100 MHz ticks, the three segment lengths in
  * shader clocks, XCC and HW ids) of every following dsc_conv3x3_nhwc_f16 call go to `device_buffer`; NULL switches it off */
@@ -239,7 +244,7 @@ void dsc_debug_set_conv_ring(int stages);
 size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
 int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                          int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
-                         int upsample2x, int out_nchw, int splits, int dtype, void* workspace, size_t workspace_bytes,
+                         int resample, int out_nchw, int splits, int dtype, void* workspace, size_t workspace_bytes,
                          void* stream);
 
 /*
