@@ -37,6 +37,17 @@ class VaeConfig:
         return VaeConfig(block_out_channels=(32, 32, 64, 64), norm_num_groups=8)
 
 
+def _conv(conv, x, residual=None, upsample=False):
+    """3x3 / pad 1 convolution of a decoder block: dsc_conv3x3_nhwc_f16 (bias / residual / nearest-2x upsample fused) where
+    it covers the shape, else the library convolution"""
+    if ops.conv3x3_supported(x, conv.weight, upsample=upsample):
+        return ops.conv3x3(x, conv.weight, conv.bias, residual=residual, upsample=upsample)
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    h = conv(x)
+    return h if residual is None else ops.add_bias_residual(residual, h)
+
+
 class VaeResnet(nn.Module):
     def __init__(self, cin, cout, groups):
         super().__init__()
@@ -47,8 +58,10 @@ class VaeResnet(nn.Module):
         self.conv_shortcut = Conv1x1(cin, cout) if cin != cout else None
 
     def forward(self, x):
-        h = self.conv2(self.norm2(self.conv1(self.norm1(x))))
-        return self.conv_shortcut(x, residual=h) if self.conv_shortcut is not None else ops.add_bias_residual(x, h)
+        h = _conv(self.conv1, self.norm1(x))
+        if self.conv_shortcut is None:
+            return _conv(self.conv2, self.norm2(h), residual=x)          # skip add in the convolution's epilogue
+        return self.conv_shortcut(x, residual=_conv(self.conv2, self.norm2(h)))
 
 
 class VaeAttention(nn.Module):
@@ -135,6 +148,11 @@ class AutoencoderKLDecoder(nn.Module):
             for res in blk.resnets:
                 x = res(x)
             if hasattr(blk, "upsamplers"):
-                x = blk.upsamplers[0]["conv"](F.interpolate(x, scale_factor=2.0, mode="nearest"))
-        x = d.conv_out(d.conv_norm_out(x).contiguous()).contiguous()
+                x = _conv(blk.upsamplers[0]["conv"], x, upsample=True)
+        hn = d.conv_norm_out(x)
+        wcl = d.conv_out.weight.contiguous(memory_format=torch.channels_last)
+        if ops.conv3x3_supported(hn, wcl):
+            x = ops.conv3x3(hn, wcl, d.conv_out.bias, out_nchw=True)          # 128 -> 3 channels, channel-major image
+        else:
+            x = d.conv_out(hn.contiguous()).contiguous()
         return type("DecoderOutput", (), {"sample": x})() if return_dict else (x,)
