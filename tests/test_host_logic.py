@@ -190,3 +190,34 @@ def test_vae_decoder_structure():
     assert "decoder.up_blocks.0.upsamplers.0.conv.weight" in keys and "post_quant_conv.bias" in keys
     n_dec = sum(p.numel() for k, p in vae.state_dict().items() if k.startswith("decoder."))
     assert n_dec == 49_490_179, n_dec
+
+
+def test_euler_scheduler_protocol_and_oracle_agree():
+    """the diffusers-scheduler protocol object of modules/model_diffusers.py against oracle/diffusers_ref.py, and
+    self-consistency of the Euler step (parity unpinned: diffusers is absent)"""
+    import numpy as np
+    from oracle import diffusers_ref
+    from diffusionspatialcontrol_amd.modules.model_diffusers import EulerDiscreteScheduler
+    for spacing in ("leading", "linspace", "trailing"):
+        s = EulerDiscreteScheduler(timestep_spacing=spacing)
+        s.set_timesteps(25)
+        ts, sig, init = diffusers_ref.euler_schedule(25, spacing)
+        np.testing.assert_array_equal(s.timesteps.numpy(), ts)
+        np.testing.assert_array_equal(s.sigmas.numpy(), sig)
+        assert abs(float(s.init_noise_sigma) - init) < 1e-6
+        assert s.sigmas[-1] == 0 and bool((s.sigmas[:-1] > s.sigmas[1:]).all())
+        assert s.sigmas.device.type == "cpu" and s.sigmas.dtype == torch.float32      # the sigma the processors receive (:352)
+    s = EulerDiscreteScheduler(timestep_spacing="linspace")
+    s.set_timesteps(10)
+    assert abs(float(s.sigmas[0]) - 14.6146) < 1e-3                      # sigma_max of the SD1.x schedule (SURVEY.md 8a a8)
+    s = EulerDiscreteScheduler()                                           # "leading" + offset 1: first timestep 901
+    s.set_timesteps(10)
+    assert float(s.timesteps[0]) == 901.0 and abs(float(s.init_noise_sigma) - (float(s.sigmas[0]) ** 2 + 1) ** 0.5) < 1e-5
+    # Euler on the exact denoiser of a point mass at x0 (eps = (x - x0) / sigma) lands on x0 at sigma = 0
+    x0 = torch.tensor([[0.3, -1.2, 2.0]])
+    x = x0 + float(s.sigmas[0]) * torch.tensor([[1.0, -0.5, 0.25]])
+    for i, t in enumerate(s.timesteps):
+        sigma = float(s.sigmas[i])
+        assert abs(float(s.scale_model_input(torch.ones(1), t)) - 1 / (sigma ** 2 + 1) ** 0.5) < 1e-6
+        x = s.step((x - x0) / sigma, t, x)[0]
+    assert torch.allclose(x, x0, atol=1e-5)

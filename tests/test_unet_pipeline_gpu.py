@@ -673,3 +673,62 @@ def test_ip_adapter_unet_and_pipeline(ops):
     assert unet.encoder_hid_proj is None and all(isinstance(p, am.AttnProcessor) for p in unet.attn_processors.values())
     c = pipe.txt2img(None, fused=True, latents=lat.clone(), **kw0)[0].float().cpu()
     assert torch.isfinite(c).all() and (c - a).abs().max().item() > 1e-3   # the image prompt did steer the result
+
+
+@pytest.mark.parametrize("n_img", [1, 2])
+def test_diffusers_scheduler_pipeline_vs_oracle(ops, n_img):
+    """the diffusers-scheduler loop (second caller of the processor boundary) with the Euler
+    scheduler vs the oracle's restatement; n_img = 2 batches two images in ONE UNet call with the std of the scores over
+    the whole call, exactly like the reference's num_images_per_prompt > 1."""
+    from oracle import diffusers_ref
+    from diffusionspatialcontrol_amd.modules.model_diffusers import EulerDiscreteScheduler, StableDiffusionPipeline_finetune
+    cfg, unet, sd, text = _tiny_setup(n_img)
+    state, ids, rs = _region_state(n_img=n_img)
+    pipe = StableDiffusionPipeline_finetune(None, None, FakeTokenizer(), unet, EulerDiscreteScheduler())
+    g = torch.Generator().manual_seed(2000)
+    lat = torch.randn(n_img, 4, 16, 16, generator=g).half()
+    pe, ne = text[n_img:n_img + 1], text[:1]
+    text_rows = torch.cat([ne.repeat(n_img, 1, 1), pe.repeat(n_img, 1, 1)]).float()
+    # ONE UNet call on all 2 * n_img rows with the whole-batch std (what every step of this loop does), tight tolerance
+    with torch.no_grad():
+        xr = torch.randn(2 * n_img, 4, 16, 16, generator=g).half()
+        tr = torch.full((2 * n_img,), 601.0)
+        rp = {"region_state": rs, "sigma": torch.tensor(3.5), "weight_func": lambda w, s, qk: w * s * qk.std()}
+        o1 = unet(xr.cuda(), tr.cuda(), text_rows.half().cuda(), cross_attention_kwargs={"region_prompt": rp}).sample.float().cpu()
+        r1 = unet_ref.unet_forward(sd, cfg, xr.float(), tr, text_rows, region_prompt={"region_state": rs, "sigma": 3.5, "weight_func": None},
+                                   n_std_groups=1)
+        sc1 = r1.abs().max().item()
+        assert (o1 - r1).abs().max().item() < 1e-2 * sc1 + 1e-3 and (o1 - r1).abs().mean().item() < 2e-3 * sc1
+    # mild guidance: tight agreement (CFG multiplies the fp16-vs-fp32 difference of eps by the guidance scale, and the
+    # Euler steps integrate it over sigma = 8.4 .. 0)
+    for gs, tol_max, tol_mean in ((1.5, 6e-2, 1.2e-2), (6.0, 2.5e-1, 4e-2)):
+        out = pipe(height=128, width=128, num_inference_steps=5, guidance_scale=gs, latents=lat.clone(), output_type="latent",
+                   prompt_embeds=pe, negative_prompt_embeds=ne, region_map_state=state, text_input_ids=ids,
+                   num_images_per_prompt=n_img)[0].float().cpu()
+        ref = diffusers_ref.euler_txt2img(sd, cfg, lat.float(), text_rows, rs, gs, 5)
+        scale = ref.abs().max().item()
+        assert torch.isfinite(out).all()
+        assert (out - ref).abs().max().item() < tol_max * scale, (gs, (out - ref).abs().max().item(), scale)
+        assert (out - ref).abs().mean().item() < tol_mean * scale, (gs, (out - ref).abs().mean().item(), scale)
+    # the region masks steer the result
+    plain = pipe(height=128, width=128, num_inference_steps=5, guidance_scale=6.0, latents=lat.clone(), output_type="latent",
+                 prompt_embeds=pe, negative_prompt_embeds=ne, num_images_per_prompt=n_img)[0].float().cpu()
+    assert (plain - out).abs().max().item() > 1e-3 * scale
+    # ControlNet residual hooks (reference u_net_condition_modify.py:1236-1245,1269-1270): zero residuals are the identity
+    with torch.no_grad():
+        x = lat[:1].repeat(2, 1, 1, 1).cuda()
+        t = torch.tensor([500.0, 500.0]).cuda()
+        base = unet(x, t, text[:2].cuda()).sample
+        skips = []
+        hooks = []
+    from diffusionspatialcontrol_amd.modules import u_net_condition_modify as um
+    shapes = [(2, 32, 16, 16)] * 3 + [(2, 32, 8, 8), (2, 64, 8, 8), (2, 64, 8, 8), (2, 64, 4, 4), (2, 64, 4, 4), (2, 64, 4, 4),
+                                       (2, 64, 2, 2), (2, 64, 2, 2), (2, 64, 2, 2)]
+    res = [torch.zeros(sh, dtype=torch.half, device="cuda").contiguous(memory_format=torch.channels_last) for sh in shapes]
+    with torch.no_grad():
+        z = unet(x, t, text[:2].cuda(), down_block_additional_residuals=res,
+                 mid_block_additional_residual=torch.zeros(2, 64, 2, 2, dtype=torch.half, device="cuda")).sample
+        res[0] = res[0] + 0.5
+        nz = unet(x, t, text[:2].cuda(), down_block_additional_residuals=res,
+                  mid_block_additional_residual=torch.zeros(2, 64, 2, 2, dtype=torch.half, device="cuda")).sample
+    assert (z - base).abs().max().item() < 5e-3 and (nz - base).abs().max().item() > 1e-3
