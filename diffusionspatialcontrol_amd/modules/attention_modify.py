@@ -122,8 +122,38 @@ def _sigma_arg(sigma, device):
     return s32
 
 
+_KERNEL_MAX_KEYS = 96      # xattn_shared.h kSMax: one 77-token text chunk (+ padding to three MFMA row tiles)
+
+
+def _region_attention_long(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale):
+    """Prompts longer than one 77-token chunk (S = 154, 231, ... from the A1111-style encoder): the fused kernels hold
+    at most 96 keys, so the reference's op sequence (attention_modify.py:90-103) runs as library kernels on the GPU -
+    scores materialised once, the std over the std group(s), bias add, softmax, PV."""
+    qh, kh, vh = (q, k, v) if layout == "bhld" else (q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+    B, H, L, d = qh.shape
+    S = kh.shape[2]
+    sf = scale if scale else 1.0 / math.sqrt(d)
+    scores = (qh @ kh.transpose(-2, -1)) * sf                                   # [B, H, L, S]
+    w_dev = resident_table(w, q.device)
+    sig = sigma.float() if (torch.is_tensor(sigma) and sigma.is_cuda) else float(sigma)   # device scalar: no host sync (graphs)
+    if weight_func is not None and not weight_func_is_default(weight_func):
+        bias = torch.broadcast_to(weight_func(w_dev, sigma, scores.reshape(-1, L, S)), w_dev.shape)
+    elif n_std_groups == 1:
+        bias = w_dev * sig * scores.float().std()
+    else:                                                                       # row b belongs to group b % n_std_groups
+        g = scores.float().reshape(B // n_std_groups, n_std_groups, -1).transpose(0, 1).reshape(n_std_groups, -1).std(dim=1)
+        Bw = w_dev.shape[0]
+        rows = (torch.arange(Bw, device=q.device) * (B * H // Bw)) // H         # table row -> batch row (b = bh // H)
+        bias = w_dev * sig * g[rows % n_std_groups].reshape(Bw, 1, 1)
+    flat = scores.reshape(-1, L, S).float() + torch.repeat_interleave(bias.float(), (B * H) // bias.shape[0], dim=0)
+    out = torch.softmax(flat, dim=-1).to(vh.dtype).reshape(B, H, L, S) @ vh
+    return out if layout == "bhld" else out.transpose(1, 2).contiguous()
+
+
 def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None,
                       comp=None):
+    if k.shape[2 if layout == "bhld" else 1] > _KERNEL_MAX_KEYS:
+        return _region_attention_long(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale)
     if weight_func is None or weight_func_is_default(weight_func):
         if packed_kv is not None and layout == "blhd":
             if comp is None:
@@ -236,7 +266,10 @@ class _RegionProcessor:
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
                                     groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp)
         elif not is_self:
-            if packed_kv is not None:
+            if S > _KERNEL_MAX_KEYS:              # long prompt without a region table: library attention
+                out = F.scaled_dot_product_attention(q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2),
+                                                     scale=sc).transpose(1, 2).contiguous()
+            elif packed_kv is not None:
                 out = ops.region_xattn_packed(q4, packed_kv, S, None, scale=sc, ref_fp16_rounding=False)
             else:
                 out = ops.region_xattn(q4, k4, v4, None, layout="blhd", scale=sc, ref_fp16_rounding=False)

@@ -102,8 +102,13 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
             raise NotImplementedError("raw IP-Adapter images, T2I-Adapter, latent previews and custom timestep lists are "
                                       "'next' rows (SURVEY.md 8f); pass ip_adapter_image_embeds for IP-Adapter")
         if prompt_embeds is None:
-            raise NotImplementedError("prompt encoding is a 'next' row: pass prompt_embeds / negative_prompt_embeds / "
-                                      "text_input_ids")
+            if prompt is None or self.tokenizer is None or self.text_encoder is None:
+                raise NotImplementedError("pass prompt_embeds / negative_prompt_embeds / text_input_ids, or construct the "
+                                          "pipeline with a tokenizer and a CLIP text encoder and pass `prompt`")
+            from .encoder_prompt_modify import encode_prompt_function
+            prompt_embeds, negative_prompt_embeds, text_input_ids = encode_prompt_function(
+                self, prompt, self._execution_device, 1, guidance_scale > 1.0, negative_prompt, clip_skip=clip_skip or None,
+                long_encode=long_encode)
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         device = self._execution_device

@@ -251,13 +251,17 @@ class StableDiffusionPipeline:
             raise NotImplementedError("hires upscale / IP-Adapter from raw images (CLIP image encoder) / ControlNet / "
                                       "T2I-Adapter / latent previews are outside the denoising hot path built here "
                                       "(SURVEY.md 8f); pass ip_adapter_image_embeds for IP-Adapter")
-        if prompt_embeds is None:
-            raise NotImplementedError("prompt encoding (CLIP + A1111 chunking, encoder_prompt_modify.py) is a 'next' "
-                                      "row: pass prompt_embeds / negative_prompt_embeds / text_input_ids")
         sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
         device = self._execution_device
         self._do_classifier_free_guidance = guidance_scale > 1.0
         cfg = self._do_classifier_free_guidance
+        if prompt_embeds is None:                                                                            # :1006-1019
+            if prompt is None or self.tokenizer is None or self.text_encoder is None:
+                raise NotImplementedError("pass prompt_embeds / negative_prompt_embeds / text_input_ids, or construct the "
+                                          "pipeline with a tokenizer and a CLIP text encoder and pass `prompt`")
+            from .encoder_prompt_modify import encode_prompt_function
+            prompt_embeds, negative_prompt_embeds, text_input_ids = encode_prompt_function(
+                self, prompt, device, 1, cfg, negative_prompt, clip_skip=clip_skip, long_encode=long_encode)
         n_img = prompt_embeds.shape[0] * num_images_per_prompt
         text = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
         if cfg:

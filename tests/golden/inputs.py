@@ -152,3 +152,80 @@ def region_state_inputs():
                              {"green dragon": {"map": rect_map(512, 512, 2, 0, 6, 4), "weight": 0.6, "mask_outsides": 0.0}}],
                             ids2, 512, 512, 1)
     return cases
+
+
+# ----------------------------------------------------------------------------- prompt encoding inputs
+class FakeClipTokenizer(FakeTokenizer):
+    """FakeTokenizer with the extra surface reference prompt_parser.py uses (:225-265): list input returning
+    {"input_ids": [...]}, get_vocab(), bos / eos ids; commas and brackets are tokens of their own (CLIP ids 267 etc.)."""
+    bos_token_id, eos_token_id = 49406, 49407
+    _PUNCT = {",": 267, "(": 7, ")": 8, "[": 9, "]": 10, ".": 269, ":": 281}
+
+    def get_vocab(self):
+        v = {k + "</w>": i for k, i in self._PUNCT.items()}
+        v.update({"((</w>": 11, "))</w>": 12, "[[</w>": 13, "plain</w>": 14})
+        return v
+
+    def _ids(self, text):
+        out = []
+        for w in text.replace(",", " , ").replace(".", " . ").replace(":", " : ").split():
+            out.append(self._PUNCT[w] if w in self._PUNCT else self.word_id(w))
+        return out
+
+    def __call__(self, text, max_length=None, truncation=True, add_special_tokens=False, **kw):
+        if isinstance(text, (list, tuple)):
+            return {"input_ids": [self._ids(t) for t in text]}
+        ids = self._ids(text)
+        if add_special_tokens:
+            ids = [self.bos_token_id] + ids + [self.eos_token_id]
+        if max_length is not None and truncation:
+            ids = ids[:max_length]
+        return type("Enc", (), {"input_ids": ids})()
+
+
+def fake_text_encoder(dim=32, layers=3, seed=11):
+    """Deterministic stand-in for CLIPTextModel with the attributes prompt_parser.py touches (:267-279): callable on a
+    [B, 77] id tensor with output_hidden_states=True -> .last_hidden_state, .hidden_states; .text_model.final_layer_norm;
+    .device / .dtype.  Token + position embedding followed by `layers` fixed tanh mixing layers."""
+    import torch
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(seed)
+            self.pos = torch.randn(77, dim, generator=g) * 0.1
+            self.mix = [torch.randn(dim, dim, generator=g) / dim ** 0.5 for _ in range(layers)]
+            self.freq = torch.rand(dim, generator=g) * 3.0 + 0.5
+            self.text_model = type("TM", (), {})()
+            self.text_model.final_layer_norm = torch.nn.LayerNorm(dim)
+            with torch.no_grad():      # a real CLIP has a learned affine: keeps the tensor mean away from 0 (mean restoration divides by it)
+                self.text_model.final_layer_norm.bias.copy_(torch.rand(dim, generator=g) * 0.5 + 0.25)
+                self.text_model.final_layer_norm.weight.copy_(torch.rand(dim, generator=g) * 0.5 + 0.75)
+            self.device, self.dtype = torch.device("cpu"), torch.float32
+
+        def forward(self, tokens, output_hidden_states=False):
+            t = tokens.to(torch.float32)
+            h = torch.sin(t[..., None] * 1e-3 * self.freq) + self.pos[: tokens.shape[1]]
+            hs = [h]
+            for m in self.mix:
+                h = torch.tanh(h @ m) + 0.5 * h
+                hs.append(h)
+            return type("Out", (), {"last_hidden_state": self.text_model.final_layer_norm(h), "hidden_states": tuple(hs)})()
+
+    return Enc()
+
+
+def prompt_cases():
+    """prompts for parse_prompt_attention / chunking / weighted encoding"""
+    long_a = ", ".join(f"item{i} with detail" for i in range(30))                 # > 75 tokens with commas near the boundary
+    long_b = " ".join(f"word{i}" for i in range(160))                            # > 150 tokens, no commas: hard splits
+    return {
+        "parse": ["normal text", "an (important) word", "(unbalanced", "\\(literal\\]", "(unnecessary)(parens)",
+                  "a (((house:1.3)) [on] a (hill:0.5), sun, (((sky))).", "", "a [b (c:1.5) d] e", "x:1.2) y", "tail \\",
+                  "one BREAK two", "(a BREAK b:1.3) c", "]stray) text[", "(((deep))) [[[less]]] (mix [in:0.8] out)",
+                  "colon: inside (a:b) and (num:+.5) (neg:-1)", "multi\nline BREAK  BREAK end"],
+        "chunk": ["a red apple, on a table", long_a, long_b, "first part BREAK second part, (weighted:1.4) end",
+                  "(" + long_a + ":1.2)", ""],
+        "encode": [["blurry, low quality", "a (red:1.3) apple on a [wooden] table"], ["", long_a],
+                   ["x BREAK y", "(a:0.5) b, c"]],
+    }

@@ -36,7 +36,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from inputs import attn_inputs, proc_inputs, ip_inputs, region_state_inputs, FakeTokenizer  # noqa: E402
+from inputs import (attn_inputs, proc_inputs, ip_inputs, region_state_inputs, FakeTokenizer, FakeClipTokenizer,  # noqa: E402
+                    fake_text_encoder, prompt_cases)
 
 REF = "/root/reference/source/modules"
 
@@ -277,6 +278,39 @@ def capture_region_encoder(er):
     print("region_encoder.npz", len(out), "arrays")
 
 
+def capture_prompt_parser(pp):
+    """prompt_parser.py (importable as is): `parse_prompt_attention` (:303-383), `FrozenCLIPEmbedderWithCustomWords`
+    chunking (`tokenize_line` :50-136) and weighted encoding (`forward` / `process_tokens` :161-221) on a deterministic
+    fake tokenizer / text encoder (tests/golden/inputs.py).  Stored as JSON text inside the npz (ragged lists)."""
+    import json
+    cases = prompt_cases()
+    out = {}
+    parsed = {}
+    for t in cases["parse"]:
+        t = t.replace("\\\\", "\\").replace("\\n", "\n")       # undo the double escaping of the recipe file
+        try:
+            parsed[t] = pp.parse_prompt_attention(t)
+        except ValueError as e:                                  # float() of a malformed weight
+            parsed[t] = "ValueError"
+    out["parse_json"] = np.frombuffer(json.dumps(parsed).encode(), dtype=np.uint8)
+    tok, enc = FakeClipTokenizer(), fake_text_encoder()
+    chunks = {}
+    for clip_skip in (1, 2):
+        emb = pp.FrozenCLIPEmbedderWithCustomWords(tok, enc, clip_skip)
+        if clip_skip == 1:
+            for t in cases["chunk"]:
+                ch, n = emb.tokenize_line(t)
+                chunks[t] = {"count": n, "tokens": [c.tokens for c in ch], "mult": [c.multipliers for c in ch]}
+        for k, pair in enumerate(cases["encode"]):
+            with torch.no_grad():
+                ids, z = emb(pair)
+            out[f"encode/{clip_skip}/{k}/ids"] = np.asarray(ids, dtype=np.int64)
+            out[f"encode/{clip_skip}/{k}/z"] = z.numpy()
+    out["chunk_json"] = np.frombuffer(json.dumps(chunks).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "prompt_parser.npz"), **out)
+    print("prompt_parser.npz", {k: np.shape(v) for k, v in out.items()})
+
+
 def capture_denoiser(ek):
     out = {}
     betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2   # scaled_linear
@@ -340,6 +374,7 @@ def main():
     capture_ip_processors(am, wf)
     capture_region_encoder(er)
     capture_denoiser(ek)
+    capture_prompt_parser(load_ref("prompt_parser.py"))
 
 
 if __name__ == "__main__":

@@ -237,3 +237,48 @@ def test_sigma_zero_and_zero_table_equal_plain_attention(full):
     # a bias that is constant along the keys of a row cancels in the softmax
     const = torch.full_like(w, 0.3)
     assert (_run(ops, q, k, v, const, sigma=2.0).float() - plain).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("n_groups", [1, 2])
+def test_long_prompt_region_attention(mods, n_groups):
+    """S = 154 keys (two 77-token chunks of the A1111-style encoder): beyond the fused kernels' 96 keys the processors run
+    the reference's op sequence as library kernels; checked against the oracle incl. per-image std groups"""
+    ops, am = mods
+    from oracle import region_attention as ra
+    g = torch.Generator().manual_seed(154 + n_groups)
+    Bc, H, L, S, d = 4, 4, 256, 154, 40
+    q = torch.randn(Bc, L, H, d, generator=g).half()
+    k = torch.randn(Bc, S, H, d, generator=g).half()
+    v = torch.randn(Bc, S, H, d, generator=g).half()
+    w = torch.zeros(Bc, L, S)
+    w[:, :100, 3:9] = 0.5
+    w[:, 150:, 80:90] = -0.3
+    ref = ra.region_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2), w, 3.0,
+                              n_std_groups=n_groups).transpose(1, 2)
+    out = am._region_attention(q.cuda(), k.cuda(), v.cuda(), w, torch.tensor(3.0), None, "blhd", n_groups)
+    assert out.shape == (Bc, L, H, d)
+    assert (out.float().cpu() - ref).abs().max().item() < 4e-3
+    # the processor takes this path for a long text and for long text without a region table
+    p = proc_inputs()
+    attn = DuckAttn(p)
+    hs = torch.from_numpy(p["hidden"]).half().cuda()
+    enc = torch.randn(2, 154, p["ctx"], generator=g).half().cuda()
+    wt = torch.zeros(2, p["L"], 154)
+    wt[:, :30, 5:12] = 0.7
+    rp = {"region_state": {p["L"]: wt}, "sigma": torch.tensor(2.0), "weight_func": lambda w_, s_, qk: w_ * s_ * qk.std()}
+
+    class CpuAttn:
+        heads, scale = p["H"], (p["C"] // p["H"]) ** -0.5
+        residual_connection, rescale_output_factor = False, 1.0
+        to_q = staticmethod(lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wq"])))
+        to_k = staticmethod(lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wk"])))
+        to_v = staticmethod(lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wv"])))
+        to_out = [lambda x: torch.nn.functional.linear(x, torch.from_numpy(p["wo"]), torch.from_numpy(p["bo"])), lambda x: x]
+
+    with torch.no_grad():
+        o = am.AttnProcessor2_0()(attn, hs, encoder_hidden_states=enc, region_prompt=rp).float().cpu()
+        o_plain = am.AttnProcessor2_0()(attn, hs, encoder_hidden_states=enc).float().cpu()
+    rp_cpu = dict(rp, weight_func=ra.default_weight_func)
+    r = ra.attn_processor2_0(CpuAttn, torch.from_numpy(p["hidden"]), enc.float().cpu(), rp_cpu)
+    r_plain = ra.attn_processor2_0(CpuAttn, torch.from_numpy(p["hidden"]), enc.float().cpu(), None)
+    assert (o - r).abs().max().item() < TOL and (o_plain - r_plain).abs().max().item() < TOL

@@ -732,3 +732,32 @@ def test_diffusers_scheduler_pipeline_vs_oracle(ops, n_img):
         nz = unet(x, t, text[:2].cuda(), down_block_additional_residuals=res,
                   mid_block_additional_residual=torch.zeros(2, 64, 2, 2, dtype=torch.half, device="cuda")).sample
     assert (z - base).abs().max().item() < 5e-3 and (nz - base).abs().max().item() > 1e-3
+
+
+def test_prompt_string_pipeline(ops):
+    """`txt2img(prompt=..., negative_prompt=...)` through the A1111-style encoder (emphasis, BREAK,
+    75-token chunks) on a fake tokenizer / text encoder == the same call with the embeddings and token ids passed in;
+    a prompt longer than one chunk (S = 154) generates through the long-prompt attention path."""
+    from inputs import FakeClipTokenizer, fake_text_encoder
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    from diffusionspatialcontrol_amd.modules.encoder_prompt_modify import encode_prompt_function
+    cfg, unet, sd, _ = _tiny_setup(1)
+    tok, enc = FakeClipTokenizer(), fake_text_encoder(dim=cfg.cross_attention_dim)
+    pipe = StableDiffusionPipeline(None, enc, tok, unet, SD15Scheduler())
+    state = {"red apple": {"map": rect_map(128, 128, 0, 0, 1, 2), "weight": 0.5, "mask_outsides": 0.0}}
+    prompt, neg = "a photo of a (red apple:1.3) on a [wooden] table, near a blue vase", "blurry, low quality"
+    g = torch.Generator().manual_seed(31)
+    lat = torch.randn(1, 4, 16, 16, generator=g).half()
+    kw = dict(height=128, width=128, num_inference_steps=4, guidance_scale=5.0, output_type="latent",
+              sampler_name="sample_dpmpp_2m", sampler_opt={"scheduler": "karras"}, region_map_state=state)
+    a = pipe.txt2img(prompt, negative_prompt=neg, latents=lat.clone(), **kw)[0].float().cpu()
+    pe, ne, ids = encode_prompt_function(pipe, prompt, "cpu", 1, True, neg, long_encode=0)
+    assert pe.shape == (1, 77, cfg.cross_attention_dim) and ids[1].shape == (1, 77)
+    b = pipe.txt2img(None, latents=lat.clone(), prompt_embeds=pe.half(), negative_prompt_embeds=ne.half(), text_input_ids=ids,
+                     **kw)[0].float().cpu()
+    assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-2 * max(1.0, b.abs().max().item())
+    long_prompt = ", ".join(f"item{i} with (detail:1.2)" for i in range(30)) + " BREAK a red apple"
+    c = pipe.txt2img(long_prompt, negative_prompt=neg, latents=lat.clone(), **kw)[0].float().cpu()
+    pe2, _, ids2 = encode_prompt_function(pipe, long_prompt, "cpu", 1, True, neg, long_encode=0)
+    assert pe2.shape[1] > 77 and pe2.shape[1] % 77 == 0 and ids2[0].shape == ids2[1].shape
+    assert torch.isfinite(c).all() and (c - a).abs().max().item() > 1e-3
