@@ -38,6 +38,12 @@ struct GemmParams {
     const half_t* x; const half_t* w; const half_t* bias; const half_t* res; half_t* out;
     int M, N, K;                 // N = rows of w (2x the output width for GEGLU)
     long long ldx, ldr, ldo;     // row strides (elements) of x, residual, out
+    // LayerNorm folding (dsc_linear_f16 header): `x` is the UN-normalised residual stream s, w = W diag(gamma), bias =
+    // beta.W + b; the epilogue applies rstd_m (acc - mu_m cvec[n]) with the row statistics of s summed from `ln_in`.
+    const float* ln_in;          // [M][ln_nb][2] per-row partial (sum, sum of squares) from the GEMM that produced s
+    const float* ln_c;           // [N] cvec[n] = sum_k w[n, k]
+    float* ln_out;               // [M][N/64][2] partials of THIS GEMM's fp16 output rows (for the next folded LayerNorm)
+    int ln_nb; float ln_inv_c, ln_eps;
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -61,6 +67,16 @@ __device__ __forceinline__ h8_t lds_frag(const half_t* tile, int row, int kchunk
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// mean and 1/std of row m of the un-normalised input from the producing GEMM's per-column-block partials (fixed order)
+__device__ __forceinline__ void row_stats(const GemmParams& p, long long m, float& mu, float& rs) {
+    const float* src = p.ln_in + m * p.ln_nb * 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < p.ln_nb; ++i) { s1 += src[2 * i]; s2 += src[2 * i + 1]; }
+    mu = s1 * p.ln_inv_c;
+    const float var = fmaxf(s2 * p.ln_inv_c - mu * mu, 0.f);
+    rs = rsqrtf(var + p.ln_eps);
+}
 
 // GEGLU: the workgroup's 64 weight rows are 32 "hidden" rows n0h.. and the 32 matching "gate" rows N/2 + n0h..
 template <bool GEGLU, int STAGES>
@@ -139,12 +155,20 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             const f4x_t v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
             *reinterpret_cast<f4x_t*>(stage + (wm * 64 + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = v;
         }
+    float* rowst = stage + BM * kEpiStride;                  // [BM][2] (mu, rstd) of the folded LayerNorm, behind the stage
+    if (p.ln_in && threadIdx.x < BM) {
+        float mu = 0.f, rs = 1.f;
+        if (m0 + (int)threadIdx.x < p.M) row_stats(p, m0 + threadIdx.x, mu, rs);
+        rowst[2 * threadIdx.x] = mu; rowst[2 * threadIdx.x + 1] = rs;
+    }
     __syncthreads();
     if (GEGLU) {
         // output tile 128 x 32: 4 chunks of 8 columns per row -> 512 chunks, 2 per thread
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int idx = threadIdx.x + c * T, row = idx >> 2, ch = idx & 3;
+            float mu = 0.f, rs = 1.f;
+            if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
             if (m0 + row < p.M) {
                 const float* sp = stage + row * kEpiStride + ch * 8;
                 const h8_t bh = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
@@ -152,8 +176,13 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
                 h8_t o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float hid = sp[j] + (float)bh[j];
-                    const float gate = sp[32 + j] + (float)bg[j];
+                    float ah = sp[j], ag = sp[32 + j];
+                    if (p.ln_in) {
+                        ah = rs * (ah - mu * p.ln_c[n0 + ch * 8 + j]);
+                        ag = rs * (ag - mu * p.ln_c[Nh + n0 + ch * 8 + j]);
+                    }
+                    const float hid = ah + (float)bh[j];
+                    const float gate = ag + (float)bg[j];
                     // diffusers: proj output is an fp16 tensor; hidden * gelu(gate) with gelu's result in fp16
                     o[j] = (half_t)((float)(half_t)hid * (float)(half_t)gelu_erf((float)(half_t)gate));
                 }
@@ -165,15 +194,32 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
-            if (m0 + row < p.M) {
+            const bool live = m0 + row < p.M;                    // a row's 8 chunks sit in 8 consecutive lanes
+            float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 1.f;
+            if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
+            if (live) {
                 const float* sp = stage + row * kEpiStride + ch * 8;
                 h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
                 if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
                 h8_t o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)(sp[j] + (float)bv[j] + (float)rv[j]);
+                for (int j = 0; j < 8; ++j) {
+                    float a = sp[j];
+                    if (p.ln_in) a = rs * (a - mu * p.ln_c[n0 + ch * 8 + j]);
+                    o[j] = (half_t)(a + (float)bv[j] + (float)rv[j]);
+                    const float f = (float)o[j];                 // statistics of the fp16 row, as the LayerNorm kernel takes them
+                    s1 += f; s2 += f * f;
+                }
                 *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
+            }
+            if (p.ln_out) {                                       // wave-uniform
+#pragma unroll
+                for (int o2 = 1; o2 < 8; o2 <<= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
+                if (live && ch == 0) {
+                    float* dst = p.ln_out + ((long long)(m0 + row) * nb + bn) * 2;
+                    dst[0] = s1; dst[1] = s2;
+                }
             }
         }
     }
@@ -183,9 +229,23 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
 
+extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
+                                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
+                                 int dtype, void* stream);
+
 extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                               int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu, int dtype,
                               void* stream) {
+    return dsc_linear_ln_f16(x, w, bias, residual, out, M, N, K, ldx, ldr, ldo, geglu, nullptr, 0, nullptr, 0.f, nullptr,
+                             dtype, stream);
+}
+
+extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
+                                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
+                                 int dtype, void* stream) {
+    if ((ln_in && (!ln_cvec || ln_nb <= 0)) || (ln_out && geglu)) return DSC_ERR_BAD_ARG;
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
     if (K % BK != 0 || N % BN != 0 || ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;
@@ -197,6 +257,7 @@ extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, co
     p.bias = static_cast<const half_t*>(bias); p.res = static_cast<const half_t*>(residual);
     p.out = static_cast<half_t*>(out);
     p.M = (int)M; p.N = N; p.K = K; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
+    p.ln_in = ln_in; p.ln_c = ln_cvec; p.ln_out = ln_out; p.ln_nb = ln_nb; p.ln_inv_c = 1.f / (float)K; p.ln_eps = ln_eps;
     const int mb = (int)((M + BM - 1) / BM);
     const int nb = geglu ? N / 64 : N / BN;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -277,6 +277,58 @@ DSC_GEMM_MIN_ROWS = 1024   # measured (tools/mb_gemm.py): the 128x64x64-tile ker
 DSC_GEMM_MAX_K = 640       # kernels for >= 1024 token rows and K <= 640; hipBLASLt's larger macro-tiles win beyond
 
 
+def linear_kernel_covers(M, N, K, dtype, geglu=False):
+    """True when dsc_linear_f16 (the hand-written MFMA GEMM with fused epilogues) takes this shape"""
+    return (USE_DSC_GEMM and dtype == torch.float16 and K % 64 == 0 and N % 64 == 0 and M >= DSC_GEMM_MIN_ROWS
+            and K <= DSC_GEMM_MAX_K and (not geglu or (N // 2) % 32 == 0))
+
+
+def fold_layernorm(weight, bias, gamma, beta):
+    """(w', b', cvec) for dsc_linear_ln_f16: LayerNorm(s; gamma, beta) @ weight.T + bias
+       == rstd (s @ w'.T - mu cvec) + b'   with w' = weight * gamma, b' = weight @ beta + bias, cvec = w'.sum(1) (fp32, of
+    the fp16-rounded w' the kernel multiplies with)."""
+    w2 = (weight.float() * gamma.float()[None, :]).to(weight.dtype).contiguous()
+    b2 = weight.float() @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return w2, b2.to(weight.dtype).contiguous(), w2.float().sum(dim=1).contiguous()
+
+
+def linear_ln(x, weight, bias, *, residual=None, geglu=False, ln=None, ln_stats=False):
+    """dsc_linear_ln_f16 (no library fallback: call only when linear_kernel_covers() says so).
+    ln = (partials [M, nb, 2] fp32, cvec [N] fp32, eps): x is the un-normalised stream, weight / bias come from
+    fold_layernorm().  ln_stats=True additionally returns the [M, N/64, 2] row partials of the output."""
+    _require_gpu(x, weight)
+    N, K = weight.shape
+    lead = x.shape[:-1]
+    M = 1
+    for v in lead:
+        M *= v
+    x2 = x.reshape(M, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or not weight.is_contiguous():
+        raise ValueError("linear_ln: unit inner stride, 16-byte aligned rows and a contiguous weight are required")
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(M, N)
+        if r2.stride(1) != 1 or r2.stride(0) % 8 != 0:
+            raise ValueError("linear_ln: residual rows must be 16-byte aligned with unit inner stride")
+    n_out = N // 2 if geglu else N
+    out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device) if ln_stats else None
+    part, cvec, eps, nb = None, None, 0.0, 0
+    if ln is not None:
+        part, cvec, eps = ln
+        nb = part.shape[1]
+        if part.shape[0] != M or part.dtype != torch.float32 or not part.is_contiguous() or cvec.numel() != N:
+            raise ValueError("linear_ln: statistics / cvec do not match the operands")
+    rc = _lib.load_library().dsc_linear_ln_f16(_p(x2), _p(weight), _p(bias), _p(r2), _p(out), M, N, K, x2.stride(0),
+                                               r2.stride(0) if r2 is not None else 0, n_out, 1 if geglu else 0,
+                                               _p(part), nb, _p(cvec), float(eps), _p(stats), 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_linear_ln_f16")
+    out = out.reshape(*lead, n_out)
+    return (out, stats) if ln_stats else out
+
+
 def linear(x, weight, bias=None, residual=None, geglu=False):
     """x @ weight.T (+ bias) (+ residual), or the fused GEGLU of [x @ weight.T + bias]; x [..., K], weight [N, K].
 

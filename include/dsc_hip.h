@@ -248,6 +248,21 @@ int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const v
                          void* stream);
 
 /*
+ * dsc_linear_f16 with a LayerNorm folded in on either side - removes the `nn.LayerNorm` launches of diffusers'
+ * BasicTransformerBlock (norm1/norm2/norm3) between the token-major GEMMs of a block:
+ *   ln_out != NULL  (producer): also writes, per output row and 64-column block, the (sum, sum of squares) of the fp16
+ *                   output row segment to ln_out[M][N/64][2] (fp32) - the statistics of the residual stream s = out.
+ *   ln_in  != NULL  (consumer): x is the UN-normalised s [M, K = C], w = W diag(gamma) (fp16), bias = beta.W^T + b,
+ *                   ln_cvec[n] = sum_k w[n,k] (fp32); per row mu, rstd come from ln_in[M][ln_nb][2] (summed in block order) and
+ *                   out[m,n] = rstd_m (acc[m,n] - mu_m cvec[n]) + bias[n]      ( = LayerNorm(s)[m,:] . W[n,:] + b[n] )
+ * geglu may be combined with ln_in, not with ln_out.  Same shape limits as dsc_linear_f16.
+ */
+int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                      int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
+                      const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
+                      int dtype, void* stream);
+
+/*
  * 3x3 / pad 1 convolution with few input channels (<= 8) - the UNet's `conv_in` (4 -> 320; reference
  * u_net_condition_modify.py:352-356,1187): x [B,Cin,H,W] channel-major fp16 (the sampler's latent layout),
  * w_t [9*Cin, Cout] = weight.reshape(Cout, Cin*9).t() (k = (ci*3 + dy)*3 + dx), out [B,H,W,Cout] channels-last, bias fused.

@@ -307,6 +307,44 @@ def test_linear_library_bias_residual(ops, M, N, K):
     assert torch.equal(yg, y)
 
 
+@pytest.mark.parametrize("M,C,N,geglu", [(8192, 320, 960, False), (2048, 640, 640, False), (8192, 320, 2560, True),
+                                          (1100, 64, 128, False)])
+def test_linear_layernorm_folding(ops, M, C, N, geglu):
+    """dsc_linear_ln_f16: producer GEMM emits row statistics, consumer GEMM applies the folded LayerNorm
+    == add + LayerNorm + linear of the three-launch path"""
+    g = torch.Generator().manual_seed(M + C + N)
+    a = torch.randn(M, C, generator=g).half().cuda()
+    wo = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    bo = (torch.randn(C, generator=g) * 0.2).half().cuda()
+    x = (torch.randn(M, C, generator=g) * 2 + 0.7).half().cuda()                  # residual stream with a non-zero mean
+    gamma = (torch.randn(C, generator=g) * 0.3 + 1).half().cuda()
+    beta = (torch.randn(C, generator=g) * 0.2).half().cuda()
+    w = (torch.randn(N, C, generator=g) / math.sqrt(C)).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.2).half().cuda()
+    assert ops.linear_kernel_covers(M, C, C, torch.float16) and ops.linear_kernel_covers(M, N, C, torch.float16, geglu)
+    # producer: s = x + a @ wo.T + bo, with the statistics of the fp16 s rows
+    s, st = ops.linear_ln(a, wo, bo, residual=x, ln_stats=True)
+    assert torch.equal(s, ops.linear(a, wo, bo, residual=x)) and st.shape == (M, C // 64, 2)
+    sf = s.float()
+    assert torch.allclose(st[..., 0].sum(1), sf.sum(1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[..., 1].sum(1), (sf * sf).sum(1), rtol=1e-5, atol=1e-2)
+    # consumer: LayerNorm folded into the weights
+    w2, b2, cvec = ops.fold_layernorm(w, b, gamma, beta)
+    y = ops.linear_ln(s, w2, b2, geglu=geglu, ln=(st, cvec, 1e-5))
+    h = F.layer_norm(sf, (C,), gamma.float(), beta.float(), 1e-5)
+    ref = h @ w.float().t() + b.float()
+    if geglu:
+        hid, gate = ref.chunk(2, dim=-1)
+        ref = hid * F.gelu(gate)
+    err = (y.float() - ref).abs()
+    assert err.max().item() < 2e-2 * max(1.0, ref.abs().max().item()) and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+    # and against the unfused product path (LayerNorm kernel -> linear): same function to fp16 rounding
+    _, hk = ops.add_layernorm(s, None, gamma, beta)
+    y0 = ops.linear(hk, w, b, geglu=geglu)
+    assert (y.float() - y0.float()).abs().mean().item() < 2e-3
+    assert torch.equal(y, ops.linear_ln(s, w2, b2, geglu=geglu, ln=(st, cvec, 1e-5)))
+
+
 @pytest.mark.parametrize("M,C", [(8192, 320), (2048, 640), (512, 1280), (300, 64)])
 def test_linear_geglu_kernel(ops, M, C):
     g = torch.Generator().manual_seed(M + C)
