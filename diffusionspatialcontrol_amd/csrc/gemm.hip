@@ -122,6 +122,9 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
 #pragma unroll
     for (int st = 0; st < STAGES - 1; ++st)
         if (st < nk) issue(st, st);
+    // folded LayerNorm: thread t < 128 owns row m0 + t's (mean, 1/std); the partial-sum loads ride under the K loop
+    float ln_mu = 0.f, ln_rs = 1.f;
+    if (p.ln_in && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) row_stats(p, m0 + threadIdx.x, ln_mu, ln_rs);
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % STAGES;
         // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (6 DMA instructions each) are outstanding
@@ -156,11 +159,7 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             *reinterpret_cast<f4x_t*>(stage + (wm * 64 + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = v;
         }
     float* rowst = stage + BM * kEpiStride;                  // [BM][2] (mu, rstd) of the folded LayerNorm, behind the stage
-    if (p.ln_in && threadIdx.x < BM) {
-        float mu = 0.f, rs = 1.f;
-        if (m0 + (int)threadIdx.x < p.M) row_stats(p, m0 + threadIdx.x, mu, rs);
-        rowst[2 * threadIdx.x] = mu; rowst[2 * threadIdx.x + 1] = rs;
-    }
+    if (p.ln_in && threadIdx.x < BM) { rowst[2 * threadIdx.x] = ln_mu; rowst[2 * threadIdx.x + 1] = ln_rs; }
     __syncthreads();
     if (GEGLU) {
         // output tile 128 x 32: 4 chunks of 8 columns per row -> 512 chunks, 2 per thread
@@ -174,12 +173,19 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
                 const h8_t bh = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
                 const h8_t bg = *reinterpret_cast<const h8_t*>(p.bias + Nh + n0 + ch * 8);
                 h8_t o;
+                float ch_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.ln_in) {
+                    const f4x_t a0 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8), a1 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8 + 4);
+                    const f4x_t g0 = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ch * 8), g1 = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ch * 8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ch_[j] = a0[j]; ch_[4 + j] = a1[j]; cg_[j] = g0[j]; cg_[4 + j] = g1[j]; }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float ah = sp[j], ag = sp[32 + j];
                     if (p.ln_in) {
-                        ah = rs * (ah - mu * p.ln_c[n0 + ch * 8 + j]);
-                        ag = rs * (ag - mu * p.ln_c[Nh + n0 + ch * 8 + j]);
+                        ah = rs * (ah - mu * ch_[j]);
+                        ag = rs * (ag - mu * cg_[j]);
                     }
                     const float hid = ah + (float)bh[j];
                     const float gate = ag + (float)bg[j];
@@ -203,10 +209,16 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
                 if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
                 if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
                 h8_t o;
+                float cv_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.ln_in) {
+                    const f4x_t a0 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8), a1 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { cv_[j] = a0[j]; cv_[4 + j] = a1[j]; }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float a = sp[j];
-                    if (p.ln_in) a = rs * (a - mu * p.ln_c[n0 + ch * 8 + j]);
+                    if (p.ln_in) a = rs * (a - mu * cv_[j]);
                     o[j] = (half_t)(a + (float)bv[j] + (float)rv[j]);
                     const float f = (float)o[j];                 // statistics of the fp16 row, as the LayerNorm kernel takes them
                     s1 += f; s2 += f * f;
@@ -246,6 +258,7 @@ extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias,
                                  const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
                                  int dtype, void* stream) {
     if ((ln_in && (!ln_cvec || ln_nb <= 0)) || (ln_out && geglu)) return DSC_ERR_BAD_ARG;
+    if (ln_in && !al16(ln_cvec)) return DSC_ERR_UNSUPPORTED;       // read as float4 pairs
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
     if (K % BK != 0 || N % BN != 0 || ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;

@@ -210,7 +210,10 @@ class _RegionProcessor:
 
     def __call__(self, attn, hidden_states: torch.Tensor, encoder_hidden_states=None,
                  attention_mask: Optional[torch.Tensor] = None, temb: Optional[torch.Tensor] = None, scale: float = 1.0,
-                 region_prompt=None, ip_adapter_masks=None) -> torch.Tensor:
+                 region_prompt=None, ip_adapter_masks=None, _ln_fold=None) -> torch.Tensor:
+        # _ln_fold (private, passed only by this package's BasicTransformerBlock to its own stock processors - see
+        # u_net_condition_modify.LNFold): hidden_states is the UN-normalised residual stream, the block's LayerNorm is
+        # folded into the q / qkv projection, the block's residual add into to_out, and (output, row statistics) is returned
         residual = hidden_states
         img_sequence_length = hidden_states.shape[1]              # :427 - dim 1 also for 4-D input
         ip_hidden_states = None
@@ -234,14 +237,22 @@ class _RegionProcessor:
         if is_self and fused_qkv is not None and attn.to_q.bias is None:
             # self-attention: q, k, v from ONE [3C, C] GEMM; the three [B, L, H, d] operands are strided views of it
             B, L, _ = hidden_states.shape
-            qkv = ops.linear(hidden_states, fused_qkv())
+            if _ln_fold is not None:
+                w2, b2, cvec = _ln_fold.folded(attn, "qkv", fused_qkv())
+                qkv = ops.linear_ln(hidden_states, w2, b2, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
+            else:
+                qkv = ops.linear(hidden_states, fused_qkv())
             C = qkv.shape[-1] // 3
             d = C // H
             S = L
             q4, k4, v4 = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
         else:
-            query = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias) if type(attn.to_q) is nn.Linear \
-                else attn.to_q(hidden_states)
+            if _ln_fold is not None:
+                w2, b2, cvec = _ln_fold.folded(attn, "q", attn.to_q.weight, attn.to_q.bias)
+                query = ops.linear_ln(hidden_states, w2, b2, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
+            else:
+                query = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias) if type(attn.to_q) is nn.Linear \
+                    else attn.to_q(hidden_states)
             if is_self:
                 encoder_hidden_states = hidden_states
             elif attn.norm_cross:
@@ -279,6 +290,9 @@ class _RegionProcessor:
         if self.is_ip_adapter:
             hidden_states = self._ip_branch(attn, q4, hidden_states, ip_hidden_states, ip_adapter_masks, sc)
         to_out = attn.to_out[0]
+        if _ln_fold is not None:
+            # the block's `x = attn(norm(x)) + x` add and the next LayerNorm's row statistics ride in this GEMM's epilogue
+            return ops.linear_ln(hidden_states, to_out.weight, to_out.bias, residual=_ln_fold.residual, ln_stats=True)
         hidden_states = ops.linear(hidden_states, to_out.weight, to_out.bias) if type(to_out) is nn.Linear \
             else to_out(hidden_states)
         hidden_states = attn.to_out[1](hidden_states)

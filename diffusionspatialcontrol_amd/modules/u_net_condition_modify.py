@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
-from .attention_modify import AttnProcessor2_0
+from .attention_modify import AttnProcessor, AttnProcessor2_0
 
 
 class ImageProjection(nn.Module):
@@ -297,6 +297,23 @@ class FeedForward(nn.Module):
         return ops.linear(h, self.net[2].weight, self.net[2].bias, residual=residual)   # net[1] is Dropout(0)
 
 
+class LNFold:
+    """What BasicTransformerBlock hands to its attention processor when the LayerNorm in front of the attention is folded
+    into the projection GEMM (dsc_linear_ln_f16): the norm module, the row statistics of the un-normalised stream (emitted
+    by the GEMM that produced it) and the stream itself as the residual of to_out."""
+
+    __slots__ = ("norm", "stats", "residual")
+
+    def __init__(self, norm, stats, residual):
+        self.norm, self.stats, self.residual = norm, stats, residual
+
+    def folded(self, owner, key, weight, bias=None):
+        """(W diag(gamma), W beta + b, row sums) of `weight` under self.norm, cached on `owner`"""
+        n = self.norm
+        deps = (weight, n.weight, n.bias) + (() if bias is None else (bias,))
+        return _derived(owner, "lnfold_" + key, deps, lambda: ops.fold_layernorm(weight, bias, n.weight, n.bias))
+
+
 class BasicTransformerBlock(nn.Module):
     def __init__(self, dim, heads, dim_head, cross_attention_dim):
         super().__init__()
@@ -307,8 +324,32 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
-    def forward(self, x, encoder_hidden_states, cross_attention_kwargs):
+    def _can_fold(self, x, stats):
+        """The three LayerNorms disappear into the neighbouring GEMMs when every one of those GEMMs runs on
+        dsc_linear_ln_f16 and both attentions carry this package's stock processors (the private `_ln_fold` protocol)."""
+        if stats is None or not x.is_cuda or x.dim() != 3:
+            return False
+        M, C = x.shape[0] * x.shape[1], x.shape[2]
+        cover = ops.linear_kernel_covers
+        if not (cover(M, 3 * C, C, x.dtype) and cover(M, C, C, x.dtype) and cover(M, 8 * C, C, x.dtype, True)):
+            return False
+        for a in (self.attn1, self.attn2):
+            if type(a.processor) not in (AttnProcessor2_0, AttnProcessor) or a.to_q.bias is not None \
+                    or type(a.to_q) is not nn.Linear or type(a.to_out[0]) is not nn.Linear \
+                    or a.spatial_norm is not None or a.group_norm is not None or a.residual_connection \
+                    or a.rescale_output_factor != 1.0 or a.inner_dim != C:
+                return False
+        return True
+
+    def forward(self, x, encoder_hidden_states, cross_attention_kwargs, stats=None):
         kw = cross_attention_kwargs or {}
+        if ops.USE_LN_FOLD and self._can_fold(x, stats):
+            x, st = self.attn1(x, None, _ln_fold=LNFold(self.norm1, stats, x), **kw)
+            x, st = self.attn2(x, encoder_hidden_states, _ln_fold=LNFold(self.norm2, st, x), **kw)
+            f = LNFold(self.norm3, st, None)
+            w2, b2, cvec = f.folded(self.ff, "geglu", self.ff.net[0].proj.weight, self.ff.net[0].proj.bias)
+            h = ops.linear_ln(x, w2, b2, geglu=True, ln=(st, cvec, self.norm3.eps))
+            return ops.linear(h, self.ff.net[2].weight, self.ff.net[2].bias, residual=x)
         # `x = attn(norm(x)) + x; h = next_norm(x)` pairs run as ONE add+LayerNorm launch (the same kwargs reach self-
         # and cross-attention, as in diffusers' BasicTransformerBlock)
         _, h = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
@@ -335,9 +376,14 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, encoder_hidden_states, cross_attention_kwargs):
         b, c, h, w = x.shape
         t = _tokens(self.norm(x))                               # channels-last: the token view is free
-        t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
-        for blk in self.transformer_blocks:
-            t = blk(t, encoder_hidden_states, cross_attention_kwargs)
+        w_in = self.proj_in.weight.flatten(1)
+        st = None
+        if ops.USE_LN_FOLD and t.is_cuda and ops.linear_kernel_covers(t.shape[0] * t.shape[1], c, c, t.dtype):
+            t, st = ops.linear_ln(t, w_in, self.proj_in.bias, ln_stats=True)   # row statistics for the first block's norm1
+        else:
+            t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
+        for i, blk in enumerate(self.transformer_blocks):
+            t = blk(t, encoder_hidden_states, cross_attention_kwargs, stats=st if i == 0 else None)
         if self.use_linear_projection:
             t = ops.linear(t, self.proj_out.weight, self.proj_out.bias, residual=_tokens(x))
         else:

@@ -275,6 +275,7 @@ USE_LT_RESIDUAL = os.environ.get("DSC_LT_RESIDUAL", "1") != "0"   # GEMMs left t
 USE_DSC_GEMM = True        # route qualifying linears to dsc_linear_f16 (False: always hipBLASLt through torch)
 DSC_GEMM_MIN_ROWS = 1024   # measured (tools/mb_gemm.py): the 128x64x64-tile kernel beats hipBLASLt + separate epilogue
 DSC_GEMM_MAX_K = 640       # kernels for >= 1024 token rows and K <= 640; hipBLASLt's larger macro-tiles win beyond
+USE_LN_FOLD = os.environ.get("DSC_LN_FOLD", "1") != "0"   # BasicTransformerBlock: LayerNorms folded into the GEMMs (dsc_linear_ln_f16)
 
 
 def linear_kernel_covers(M, N, K, dtype, geglu=False):

@@ -523,6 +523,64 @@ def test_sd15_unet_step_full_size(ops):
     scale = outs[0].float().abs().max().item()
     assert torch.equal(outs[0], outs[1])
     assert (plain.float() - outs[0].float()).abs().max().item() > 1e-3 * scale   # the region bias is live
+    # LayerNorm folding (dsc_linear_ln_f16) on vs off: the same function up to fp16 rounding of one intermediate
+    ops.USE_LN_FOLD = False
+    try:
+        with torch.no_grad():
+            unfolded = unet(x, t, enc, cross_attention_kwargs={"region_prompt": rp}).sample
+    finally:
+        ops.USE_LN_FOLD = True
+    assert (unfolded.float() - outs[0].float()).abs().max().item() < 1e-2 * scale
+
+
+@pytest.mark.parametrize("C,heads,hw", [(320, 8, 64), (640, 8, 32)])
+def test_transformer_block_layernorm_folding(ops, C, heads, hw):
+    """Transformer2DModel with the three LayerNorms of its block folded into the neighbouring GEMMs against the unfolded
+    launch sequence and against the fp32 torch restatement of the block on the same weights."""
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import Transformer2DModel
+    torch.manual_seed(C)
+    with torch.device("cuda"):
+        tr = Transformer2DModel(C, heads, 1, 768, 32, False)
+    for n_ in (tr.transformer_blocks[0].norm1, tr.transformer_blocks[0].norm2, tr.transformer_blocks[0].norm3):
+        torch.nn.init.normal_(n_.weight, 1.0, 0.3)
+        torch.nn.init.normal_(n_.bias, 0.0, 0.2)
+    tr = tr.half().eval()
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(2, C, hw, hw, generator=g) * 1.5 + 0.3).half().cuda().contiguous(memory_format=torch.channels_last)
+    enc = torch.randn(2, 77, 768, generator=g).half().cuda()
+    with torch.no_grad():
+        assert ops.USE_LN_FOLD and tr.transformer_blocks[0]._can_fold(torch.empty(2, hw * hw, C, device="cuda", dtype=torch.float16), True)
+        y1 = tr(x, enc, None)
+        ops.USE_LN_FOLD = False
+        try:
+            y0 = tr(x, enc, None)
+        finally:
+            ops.USE_LN_FOLD = True
+        assert torch.equal(y1, tr(x, enc, None))
+        # fp32 restatement (diffusers BasicTransformerBlock order of operations)
+        blk = tr.transformer_blocks[0]
+        f = lambda m: m.float()
+        xf = x.float()
+        h = F.group_norm(xf, 32, f(tr.norm.weight), f(tr.norm.bias), 1e-6)
+        tks = h.permute(0, 2, 3, 1).reshape(2, hw * hw, C) @ f(tr.proj_in.weight).flatten(1).t() + f(tr.proj_in.bias)
+
+        def attn(a, hn, ctx):
+            q, k, v = hn @ f(a.to_q.weight).t(), ctx @ f(a.to_k.weight).t(), ctx @ f(a.to_v.weight).t()
+            sp = lambda z: z.unflatten(-1, (heads, C // heads)).transpose(1, 2)
+            o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).flatten(2)
+            return o @ f(a.to_out[0].weight).t() + f(a.to_out[0].bias)
+        ln = lambda n_, z: F.layer_norm(z, (C,), f(n_.weight), f(n_.bias), n_.eps)
+        hn = ln(blk.norm1, tks)
+        tks = tks + attn(blk.attn1, hn, hn)
+        tks = tks + attn(blk.attn2, ln(blk.norm2, tks), enc.float())
+        pr = ln(blk.norm3, tks) @ f(blk.ff.net[0].proj.weight).t() + f(blk.ff.net[0].proj.bias)
+        hid, gate = pr.chunk(2, dim=-1)
+        tks = tks + (hid * F.gelu(gate)) @ f(blk.ff.net[2].weight).t() + f(blk.ff.net[2].bias)
+        ref = (tks @ f(tr.proj_out.weight).flatten(1).t() + f(tr.proj_out.bias)).reshape(2, hw, hw, C).permute(0, 3, 1, 2) + xf
+    scale = ref.abs().max().item()
+    e1, e0 = (y1.float() - ref).abs().max().item(), (y0.float() - ref).abs().max().item()
+    assert e1 < 1e-2 * scale and e0 < 1e-2 * scale, (e1, e0, scale)
+    assert e1 < 2.0 * e0 + 1e-3 * scale, (e1, e0)             # folding is not less accurate than the unfolded sequence
 
 
 def _region_tables(levels, S, seed=0):
