@@ -12,7 +12,8 @@ class DscLibraryError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libdsc_hip.so")
+    # DSC_LIB_PATH: A/B measurements against another build of the same ABI (tools/, never the tests)
+    return os.environ.get("DSC_LIB_PATH") or os.path.join(_HERE, "libdsc_hip.so")
 
 
 def header_path():

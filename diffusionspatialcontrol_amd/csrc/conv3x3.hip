@@ -301,6 +301,23 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
         else slice(std::integral_constant<int, 0>{}, c);
     }
     if (p.stamps) { st2 = __builtin_amdgcn_s_memrealtime(); sc2 = __builtin_amdgcn_s_memtime(); }
+    // residual pixels of this thread's four output chunks: issued before the staging pass so that their latency hides
+    // under it (the skip tensor was written by an earlier kernel: Infinity Cache / HBM)
+    h8_t rpre[4];
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx) {
+        rpre[cidx] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.res && p.splits == 1 && !p.nchw) {
+            const int idx = threadIdx.x + cidx * T, m = idx >> 3, ch = idx & 7;
+            const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
+            const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
+            const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
+            long long gp = ((long long)b * p.H + yy) * p.W + xx;
+            bool live = b >= 0 && n0 + ch * 8 + 8 <= p.Cout;
+            if (p.sub2) { live = live && !((yy | xx) & 1); gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1); }
+            if (live) rpre[cidx] = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + n0 + ch * 8);
+        }
+    }
     __syncthreads();
 
     // ---- epilogue: stage[m][n] fp32
@@ -334,9 +351,9 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
             const int c0 = n0 + ch * 8;
             if (c0 >= p.Cout) continue;                              // channel padding of a ragged last tile
             if (c0 + 8 <= p.Cout && !p.nchw) {
-                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0};
+                const h8_t rv = rpre[cidx];
                 if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + c0);
-                if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + c0);
                 h8_t o;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)rv[jj]);

@@ -147,6 +147,17 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             acc[1] = mfma_32x32x16(wf, x1, acc[1]);
         }
     }
+    // residual rows of this thread's four output chunks: issued before the staging pass so that their latency (HBM /
+    // Infinity Cache: the residual stream was written by an earlier kernel) hides under it
+    h8_t rpre[4];
+    if (!GEGLU) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
+            rpre[c] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.res && m0 + row < p.M) rpre[c] = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
+        }
+    }
     __syncthreads();                                         // all MFMA operand reads done: LDS becomes the epilogue stage
 
     // ---- epilogue stage: stage[m][n] fp32; acc[mt] element i <-> n = wn*32 + (i&3) + 8(i>>2) + 4hh, m = wm*64 + mt*32 + r
@@ -205,9 +216,9 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
             if (live) {
                 const float* sp = stage + row * kEpiStride + ch * 8;
-                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0};
+                const h8_t rv = rpre[c];
                 if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
-                if (p.res) rv = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
                 h8_t o;
                 float cv_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (p.ln_in) {
