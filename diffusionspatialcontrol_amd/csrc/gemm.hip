@@ -66,8 +66,6 @@ __device__ __forceinline__ h8_t lds_frag(const half_t* tile, int row, int kchunk
     return *reinterpret_cast<const h8_t*>(tile + row * BK + ((kchunk ^ ((row >> 1) & 7)) << 3));
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-
 // mean and 1/std of row m of the un-normalised input from the producing GEMM's per-column-block partials (fixed order)
 __device__ __forceinline__ void row_stats(const GemmParams& p, long long m, float& mu, float& rs) {
     const float* src = p.ln_in + m * p.ln_nb * 2;

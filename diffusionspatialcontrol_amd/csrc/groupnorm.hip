@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kT) void geglu_kernel(const half_t* x, half_t* y, l
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gte = (float)gv[j];
-            const float gel = 0.5f * gte * (1.f + erff(gte * 0.70710678118654752f));
+            const float gel = gelu_erf(gte);
             // diffusers GEGLU: hidden_states * gelu(gate); gelu output is an fp16 tensor before the product
             o[j] = (half_t)((float)hv[j] * (float)(half_t)gel);
         }
