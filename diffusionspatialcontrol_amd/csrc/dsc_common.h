@@ -21,6 +21,12 @@ __device__ __forceinline__ f16x_t mfma_32x32x16(h8_t a, h8_t b, f16x_t c) {
 
 __device__ __forceinline__ float round_f16(float x) { return (float)(half_t)x; }
 
+// SiLU x / (1 + e^-x) on v_exp_f32 + v_rcp_f32 (relative error ~2e-7) instead of the IEEE division sequence
+// (v_div_scale / v_div_fmas / v_div_fixup: ~10 VALU instructions per element of every GroupNorm+SiLU output)
+__device__ __forceinline__ float silu_f(float x) {
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
 // GELU with the exact (erf) definition diffusers' GEGLU uses, branch-free: erfc(|z|), z = x / sqrt 2, from Abramowitz &
 // Stegun 7.1.26 (|error| <= 1.5e-7, three orders below the fp16 resolution of the result) - 5 FMAs, one v_rcp_f32 and one
 // v_exp_f32 instead of the device library's two-branch erff (~45 VALU instructions per element with both branches live

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(kT) void gn_apply(GnParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = (float)val[j] * ga + be;
-            if (p.silu) f = f / (1.f + __expf(-f));
+            if (p.silu) f = silu_f(f);
             o[j] = (half_t)f;
         }
         *reinterpret_cast<h8_t*>(out + v * 8) = o;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kT) void gn_apply_scalar(GnParams p, long long n, l
         const int c = g * p.cpg + (int)(e / p.hw);
         const float ga = (float)p.gamma[c] * rstd, be = (float)p.beta[c] - mean * ga;
         float f = (float)base[e] * ga + be;
-        if (p.silu) f = f / (1.f + __expf(-f));
+        if (p.silu) f = silu_f(f);
         out[e] = (half_t)f;
     }
 }

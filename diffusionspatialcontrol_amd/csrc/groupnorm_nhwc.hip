@@ -56,12 +56,23 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ssum[slice * p.C + c8 * 8 + j] = s[j]; ssq[slice * p.C + c8 * 8 + j] = q[j]; }
     __syncthreads();
-    // per-group totals: thread g sums its cpg channels over the k slices (fixed order), in fp64
+    // per-channel totals over the k slices (threads stride the channels, fixed order, fp64) into tot[C][2] behind the
+    // slice sums, then per-group totals over the cpg channels: two short dependent chains (k, cpg) instead of one of
+    // k * cpg fp64 adds on 32 threads
+    double* tot = reinterpret_cast<double*>(ssq + p.k * p.C);
+    if (p.k > 1) {                                            // one slice: the group sum reads the slice values directly
+        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+            double c1 = 0.0, c2 = 0.0;
+            for (int sl = 0; sl < p.k; ++sl) { c1 += (double)ssum[sl * p.C + c]; c2 += (double)ssq[sl * p.C + c]; }
+            tot[2 * c] = c1; tot[2 * c + 1] = c2;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x < p.G) {
         const int g = threadIdx.x;
         double a1 = 0.0, a2 = 0.0;
-        for (int sl = 0; sl < p.k; ++sl)
-            for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += (double)ssum[sl * p.C + c]; a2 += (double)ssq[sl * p.C + c]; }
+        if (p.k > 1) for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += tot[2 * c]; a2 += tot[2 * c + 1]; }
+        else for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += (double)ssum[c]; a2 += (double)ssq[c]; }
         double* dst = p.partials + (((long long)b * p.nchunk + chunk) * p.G + g) * 2;
         dst[0] = a1; dst[1] = a2;
     }
@@ -88,6 +99,18 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     __shared__ float mean_s[64], rstd_s[64];
     __shared__ double red[8 * 64 * 2];
     const int b = blockIdx.x / p.anchunk, chunk = blockIdx.x % p.anchunk;
+    // this thread's first rows go out before the statistics are read: their latency hides the (mean, rstd) fetch and fold
+    constexpr int kPre = 4;
+    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
+    const int r0 = chunk * p.arows, r1 = min(r0 + p.arows, p.HW);
+    const long long off = (long long)b * p.HW * p.C + c8 * 8;
+    h8_t pre[kPre];
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+        const int row = r0 + slice + i * p.k;
+        pre[i] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < r1) pre[i] = *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C);
+    }
     if (p.inline_stats) {
         // few statistics chunks (<= 32 per image): every apply workgroup adds them itself, in a fixed order - 16 KB of
         // L2 reads instead of a third launch.  thread (g, part): chunks part, part + P, ...; then the P parts in order
@@ -115,7 +138,6 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
         rstd_s[threadIdx.x] = p.stats[((long long)b * p.G + threadIdx.x) * 2 + 1];
     }
     __syncthreads();
-    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
     float sc[8], sh[8];
     {
         const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + c8 * 8);
@@ -129,19 +151,23 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
             sh[j] = (float)be[j] + ((float)ad[j] - mean_s[g]) * sc[j];
         }
     }
-    const int r0 = chunk * p.arows, r1 = min(r0 + p.arows, p.HW);
-    const long long off = (long long)b * p.HW * p.C + c8 * 8;
-    for (int row = r0 + slice; row < r1; row += p.k) {
-        const h8_t v = *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C);
+    auto emit = [&](int row, const h8_t& v) {
         h8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float f = (float)v[j] * sc[j] + sh[j];
-            if (p.silu) f = f / (1.f + __expf(-f));
+            if (p.silu) f = silu_f(f);
             o[j] = (half_t)f;
         }
         *reinterpret_cast<h8_t*>(p.y + off + (long long)row * p.C) = o;
+    };
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+        const int row = r0 + slice + i * p.k;
+        if (row < r1) emit(row, pre[i]);
     }
+    for (int row = r0 + slice + kPre * p.k; row < r1; row += p.k)
+        emit(row, *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C));
 }
 
 // Small images (the 8x8 / 16x16 UNet levels): ONE launch, one workgroup per (image, group).  The group's slab
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float f = (v[i][j] - mean) * rstd * (float)ga[j] + (float)be[j];
-                if (p.silu) f = f / (1.f + __expf(-f));
+                if (p.silu) f = silu_f(f);
                 o[j] = (half_t)f;
             }
             *reinterpret_cast<h8_t*>(p.y + base + (long long)pix * p.C + j8 * 8) = o;
@@ -317,7 +343,7 @@ __global__ __launch_bounds__(T) void gn_nhwc_bundle(GnN p, GnBundle q) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float f = (float)x[i][j] * sc[j] + sh[j];
-                if (p.silu) f = f / (1.f + __expf(-f));
+                if (p.silu) f = silu_f(f);
                 o[j] = (half_t)f;
             }
             *reinterpret_cast<h8_t*>(p.y + base + (long long)pix * p.C) = o;
@@ -449,7 +475,12 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     if (g_gn_mode == 4) {                                        // diagnostics: the three-launch form
         p.rows = p.arows; p.nchunk = p.anchunk; p.inline_stats = 0;
     }
-    hipLaunchKernelGGL(gn_nhwc_stats, dim3(B * p.nchunk), block, (size_t)2 * p.k * C * sizeof(float), st, p);
+    const size_t stats_lds = (size_t)2 * p.k * C * sizeof(float) + (size_t)2 * C * sizeof(double);
+    if (stats_lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_nhwc_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    }
+    hipLaunchKernelGGL(gn_nhwc_stats, dim3(B * p.nchunk), block, stats_lds, st, p);
     if (!p.inline_stats) hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
     hipLaunchKernelGGL(gn_nhwc_apply, dim3(B * p.anchunk), block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;

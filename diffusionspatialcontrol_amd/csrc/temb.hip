@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const void* xin, const
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float y = round_f16(acc[m] + b);
-            if (flags & DSC_ROWS_SILU_OUT) y = y / (1.f + __expf(-y));
+            if (flags & DSC_ROWS_SILU_OUT) y = silu_f(y);
             out[m * ldo + n] = (half_t)y;
         }
     }
