@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from diffusionspatialcontrol_amd import ops, _lib
 lib = _lib.load_library(); dev = "cuda"
-for (B, cin, cout, hw, splits) in [(2, 320, 320, 64, 1), (1, 320, 320, 64, 1), (2, 960, 320, 64, 1), (2, 1280, 1280, 16, 5), (2, 1280, 1280, 8, 10), (16, 320, 320, 64, 1)]:
+for (B, cin, cout, hw, splits) in [(2, 320, 320, 64, 1), (2, 960, 320, 64, 1), (2, 1280, 1280, 16, 5), (2, 1280, 1280, 8, 10)]:
     x = torch.randn(B, cin, hw, hw, device=dev).half().contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)).half().contiguous(memory_format=torch.channels_last)
     for _ in range(3): ops.conv3x3(x, w, None, splits=splits)
