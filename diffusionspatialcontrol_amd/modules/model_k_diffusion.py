@@ -109,14 +109,14 @@ class StableDiffusionPipeline:
         return getattr(importlib.import_module(sampling.__name__), scheduler_type)
 
     def get_sigmas(self, steps, params):
-        """reference :848-882 (karras / default branches)"""
+        """reference :848-882"""
         discard = params.get("discard_next_to_last_sigma", False)
         steps += 1 if discard else 0
-        if params.get("scheduler", None) == "karras":
+        named = {"karras": sampling.get_sigmas_karras, "exponential": sampling.get_sigmas_exponential,
+                 "polyexponential": sampling.get_sigmas_polyexponential}
+        if params.get("scheduler", None) in named:
             smin, smax = self.k_diffusion_model.sigmas[0].item(), self.k_diffusion_model.sigmas[-1].item()
-            sigmas = sampling.get_sigmas_karras(n=steps, sigma_min=smin, sigma_max=smax, device=self.device)
-        elif params.get("scheduler", None) in ("exponential", "polyexponential"):
-            raise NotImplementedError("only the karras and default schedules are on the hot path")
+            sigmas = named[params["scheduler"]](n=steps, sigma_min=smin, sigma_max=smax, device=self.device)
         else:
             sigmas = self.k_diffusion_model.get_sigmas(steps)
         if discard:
@@ -144,8 +144,16 @@ class StableDiffusionPipeline:
         else:
             extra["sigmas"] = sigmas
         if sampler_opt.get("brownian_noise", False):
-            raise NotImplementedError("SDE samplers are outside the hot path")
+            extra["noise_sampler"] = self.create_noise_sampler(latents, sigmas, steps, seed)
+        if sampler_opt.get("solver_type", None) == "heun":
+            extra["solver_type"] = "heun"
         return extra
+
+    def create_noise_sampler(self, x, sigmas, p, seed):
+        """reference :884-890 (BrownianTreeNoiseSampler seeded per generation; see sampling.BrownianTreeNoiseSampler for
+        what the torchsde-free counterpart keeps of it)"""
+        sigma_min, sigma_max = sigmas[sigmas > 0].min(), sigmas.max()
+        return sampling.BrownianTreeNoiseSampler(x, sigma_min, sigma_max, seed=seed)
 
     @torch.no_grad()
     def decode_latents(self, latents):

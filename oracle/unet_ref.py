@@ -124,7 +124,8 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
     return _conv(sd, "conv_out", F.silu(_gn(sd, "conv_norm_out", x, G, eps)))
 
 
-def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None):
+def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None,
+                 sampler=None, sampler_kwargs=None):
     """txt2img's loop for n_img images in the row layout [u_0.., c_0..]; returns the final latents (fp32).
 
     latents: initial noise ALREADY multiplied by sqrt(sigma_0^2 + 1) (model_k_diffusion.py:1043);
@@ -146,6 +147,10 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
         return kd.cfg_combine(out, guidance_scale)                                    # :1162-1166
 
     x = latents.float()
+    if sampler is not None:
+        # another caller of the same model_fn (k-diffusion call shape `sampler(model, x, sigmas=..., **kw)`): the test
+        # hands in the sampler under test, the oracle supplies the fp32 CPU model it drives
+        return sampler(model_fn, x, sigmas=torch.tensor(sig, dtype=torch.float32), **(sampler_kwargs or {}))
     old = None
     for i, (a, b, c) in enumerate(kd.dpmpp_2m_coeffs(sig) if sig[-1] == 0 else _coeffs_partial(sig)):
         d = model_fn(x, torch.full((n_img,), sig[i]))

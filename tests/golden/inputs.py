@@ -229,3 +229,37 @@ def prompt_cases():
         "encode": [["blurry, low quality", "a (red:1.3) apple on a [wooden] table"], ["", long_a],
                    ["x BREAK y", "(a:0.5) b, c"]],
     }
+
+
+# ----------------------------------------------------------------------------- samplers (tests/golden/samplers_extra.npz)
+def analytic_denoiser(x, sigma, **extra_args):
+    """A smooth stand-in for the CFG-combined denoiser: the exact posterior mean for N(0, 1.3^2) data plus a bounded
+    non-linear term, so that every slope / stage of a sampler contributes to the result."""
+    import torch
+    s = sigma.reshape(-1, *([1] * (x.ndim - 1))).to(x.dtype)
+    return x * (1.69 / (1.69 + s * s)) + 0.1 * torch.tanh(x) * s / (1 + s)
+
+
+def sampler_cases():
+    """name -> (function name in samplers_extra_k_diffusion, number of sigmas, kwargs, torch seed)"""
+    return {
+        "restart_25": ("restart_sampler", 25, {}, 3),                       # automatic list: one restart of 9 steps
+        "restart_40": ("restart_sampler", 40, {}, 4),                       # automatic list: steps // 4, twice
+        "restart_10": ("restart_sampler", 10, {}, 5),                       # no restart below 20 steps
+        "restart_explicit": ("restart_sampler", 12, {"restart_list": {0.3: [4, 2, 3.0]}, "s_noise": 0.7}, 6),
+        "ddpm_15": ("sample_ddpm", 15, {}, 7),
+        "lcm_6": ("sample_lcm", 6, {}, 8),
+        "heunpp2_12": ("sample_heunpp2", 12, {}, 9),
+        "heunpp2_churn": ("sample_heunpp2", 9, {"s_churn": 4.0, "s_tmin": 0.05, "s_tmax": 10.0, "s_noise": 1.003}, 10),
+    }
+
+
+def sampler_start(n_sigmas):
+    """(x0 [2,4,8,8] float64 scaled by sigma_max, Karras sigmas + trailing zero) for the SD1.5 sigma range"""
+    import torch
+    g = torch.Generator().manual_seed(1234 + n_sigmas)
+    ramp = torch.linspace(0, 1, n_sigmas, dtype=torch.float64)
+    lo, hi = 0.029167533 ** (1 / 7.0), 14.614646912 ** (1 / 7.0)
+    sigmas = torch.cat([(hi + ramp * (lo - hi)) ** 7.0, torch.zeros(1, dtype=torch.float64)])
+    x = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64) * sigmas[0]
+    return x, sigmas

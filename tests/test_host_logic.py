@@ -256,3 +256,118 @@ def test_prompt_parser_against_reference_goldens():
             np.testing.assert_array_equal(np.asarray(ids), g[f"encode/{clip_skip}/{k}/ids"])
             np.testing.assert_allclose(z.numpy(), g[f"encode/{clip_skip}/{k}/z"], rtol=1e-6, atol=1e-6)
     assert emb.get_target_prompt_token_count(0) == 75 and emb.get_target_prompt_token_count(76) == 150
+
+
+# ----------------------------------------------------------------------------- samplers (callers of the hot path)
+def _gauss_model(s0):
+    """exact denoiser for N(0, s0^2) data; the probability-flow ODE then has the closed form
+    x(sigma) = x(sigma_max) sqrt((s0^2 + sigma^2) / (s0^2 + sigma_max^2))"""
+    return lambda x, sigma, **kw: x * (s0 ** 2 / (s0 ** 2 + sigma.reshape(-1, *([1] * (x.ndim - 1))).to(x.dtype) ** 2))
+
+
+def _ode_error(fn, n, s0=1.3, **kw):
+    sig = sampling.get_sigmas_karras(n, 0.03, 14.6).double()
+    x = torch.full((2, 4), 1.0, dtype=torch.float64) * sig[0]
+    out = fn(_gauss_model(s0), x, sig, **kw)
+    return (out - x * math.sqrt(s0 ** 2 / (s0 ** 2 + float(sig[0]) ** 2))).abs().max().item()
+
+
+@pytest.mark.parametrize("name,kw,min_order", [
+    ("sample_euler", {}, 0.9), ("sample_heun", {}, 1.9), ("sample_dpm_2", {}, 1.9), ("sample_lms", {}, 2.5),
+    ("sample_euler_ancestral", {"eta": 0.0}, 0.9), ("sample_dpm_2_ancestral", {"eta": 0.0}, 1.9),
+    ("sample_dpmpp_2s_ancestral", {"eta": 0.0}, 1.5), ("sample_dpmpp_sde", {"eta": 0.0}, 1.5),
+    ("sample_dpmpp_2m_sde", {"eta": 0.0}, 1.9), ("sample_dpmpp_2m_sde", {"eta": 0.0, "solver_type": "heun"}, 1.9),
+    ("sample_dpmpp_3m_sde", {"eta": 0.0}, 1.9)])
+def test_sampler_convergence_order(name, kw, min_order):
+    """The k-diffusion samplers are un-vendored (parity unpinned): each restatement must at least solve the probability-flow
+    ODE of an analytic denoiser at its published order (eta = 0 turns the ancestral / SDE samplers into ODE solvers)."""
+    fn = getattr(sampling, name)
+    e20, e40 = _ode_error(fn, 20, **kw), _ode_error(fn, 40, **kw)
+    assert e40 < e20 and math.log2(e20 / e40) > min_order, (e20, e40)
+    assert e40 < 6e-2
+
+
+def test_sampler_eta0_reductions_and_schedules():
+    sig = sampling.get_sigmas_karras(12, 0.03, 14.6).double()
+    x = torch.randn(3, 5, generator=torch.Generator().manual_seed(1), dtype=torch.float64) * sig[0]
+    m = _gauss_model(0.8)
+    assert torch.allclose(sampling.sample_euler_ancestral(m, x, sig, eta=0.0), sampling.sample_euler(m, x, sig), atol=1e-12)
+    assert torch.allclose(sampling.sample_dpm_2_ancestral(m, x, sig, eta=0.0), sampling.sample_dpm_2(m, x, sig), atol=1e-12)
+    # DPM++ 2M SDE without noise is DPM++ 2M: same coefficients as the fused step's host scalars
+    co = sampling.dpmpp_2m_coefficients([float(v) for v in sig])
+    y, old = x.clone(), None
+    for i, (a, b, c) in enumerate(co):
+        d = m(y, sig[i] * y.new_ones(3))
+        y = a * y + b * d + (c * old if old is not None else 0.0)
+        old = d
+    assert torch.allclose(sampling.sample_dpmpp_2m_sde(m, x, sig, eta=0.0), y, atol=1e-9)
+    e = sampling.get_sigmas_exponential(10, 0.03, 14.6)
+    pe = sampling.get_sigmas_polyexponential(10, 0.03, 14.6, rho=1.0)
+    assert e.shape == (11,) and float(e[-1]) == 0.0 and torch.allclose(e, pe, rtol=1e-5)
+    assert abs(float(e[0]) - 14.6) < 1e-4 and abs(float(e[-2]) - 0.03) < 1e-6
+    assert torch.allclose(torch.log(e[:-1]).diff(), torch.log(e[:-1]).diff()[0].expand(9), atol=1e-5)
+    assert sampling.get_ancestral_step(2.0, 1.0, eta=0.0) == (1.0, 0.0)
+    dn, up = sampling.get_ancestral_step(2.0, 1.0, eta=1.0)
+    assert abs(dn ** 2 + up ** 2 - 1.0) < 1e-12 and abs(up ** 2 - 0.75) < 1e-12
+    assert abs(sum(sampling.linear_multistep_coeff(3, [4.0, 3.0, 2.5, 1.0], 2, j) for j in range(3)) - (1.0 - 2.5)) < 1e-12
+
+
+@pytest.mark.parametrize("name,n", [("sample_euler_ancestral", 120), ("sample_dpm_2_ancestral", 30),
+                                    ("sample_dpmpp_2s_ancestral", 30), ("sample_dpmpp_sde", 30), ("sample_dpmpp_2m_sde", 30),
+                                    ("sample_dpmpp_3m_sde", 30)])
+def test_stochastic_samplers_keep_the_marginal(name, n):
+    """With the exact denoiser of N(0, s0^2) data every stochastic sampler must end with samples of standard deviation s0
+    (first-order Euler a needs more steps for the same tolerance: 0.90 s0 at 30 steps, 0.97 at 120).  DPM++ SDE only passes
+    with noise increments of ONE Brownian path (its two queries per step overlap): independent draws give 0.92."""
+    s0 = 1.3
+    sig = sampling.get_sigmas_karras(n, 0.03, 14.6).double()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(20000, 1, generator=g, dtype=torch.float64) * math.sqrt(s0 ** 2 + float(sig[0]) ** 2)
+    torch.manual_seed(11)
+    out = getattr(sampling, name)(_gauss_model(s0), x, sig)
+    assert abs(out.std().item() / s0 - 1.0) < 0.04, out.std().item()
+    assert abs(out.mean().item()) < 0.05
+
+
+def test_extra_samplers_match_reference_goldens():
+    """restart / DDPM / LCM / Heun++ against outputs of the REFERENCE's samplers_extra_k_diffusion.py
+    (tests/golden/make_golden_samplers.py) on the analytic denoiser of tests/golden/inputs.py"""
+    import numpy as np
+    from inputs import analytic_denoiser, sampler_cases, sampler_start
+    from diffusionspatialcontrol_amd.modules import samplers_extra_k_diffusion as sx
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "samplers_extra.npz"))
+    for name, (fn, n, kw, seed) in sampler_cases().items():
+        x, sig = sampler_start(n)
+        calls = []
+
+        def model(xx, s, **k):
+            calls.append(float(s.reshape(-1)[0]))
+            return analytic_denoiser(xx, s)
+        torch.manual_seed(seed)
+        y = getattr(sx, fn)(model, x.clone(), sig, disable=True, **kw)
+        assert len(calls) == len(gold[name + "/model_sigmas"]), name
+        assert np.abs(np.array(calls) - gold[name + "/model_sigmas"]).max() < 1e-6, name
+        assert np.abs(y.numpy() - gold[name]).max() < 1e-6, (name, np.abs(y.numpy() - gold[name]).max())
+
+
+def test_pipeline_sampler_plumbing():
+    unet = UNet2DConditionModel(UNetConfig.tiny()).half()
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    for sched in ("karras", "exponential", "polyexponential", None):
+        s = pipe.get_sigmas(10, {"scheduler": sched} if sched else {})
+        assert s.shape == (11,) and float(s[-1]) == 0.0 and bool((s[:-1].diff() < 0).all())
+    s = pipe.get_sigmas(10, {"scheduler": "karras", "discard_next_to_last_sigma": True})
+    full = pipe.get_sigmas(11, {"scheduler": "karras"})
+    assert s.shape == (11,) and torch.equal(s[:-1], full[:-2]) and float(s[-1]) == 0.0
+    for name in ("sample_euler", "sample_euler_ancestral", "sample_lms", "sample_heun", "sample_dpm_2",
+                 "sample_dpm_2_ancestral", "sample_dpmpp_2s_ancestral", "sample_dpmpp_2m", "sample_dpmpp_sde",
+                 "sample_dpmpp_2m_sde", "sample_dpmpp_3m_sde"):                       # every k-diffusion name app.py:170-220 lists
+        assert callable(pipe.get_scheduler(name))
+    x = torch.zeros(1, 4, 8, 8)
+    sig = pipe.get_sigmas(5, {"scheduler": "karras"})
+    ex = pipe.get_sampler_extra_args_t2i(sig, 0.3, 5, {"brownian_noise": True, "solver_type": "heun"}, x, 7,
+                                         sampling.sample_dpmpp_2m_sde)
+    assert ex["eta"] == 0.3 and ex["solver_type"] == "heun" and ex["sigmas"] is sig
+    n1, n2 = ex["noise_sampler"](sig[0], sig[1]), ex["noise_sampler"](sig[1], sig[2])
+    again = pipe.create_noise_sampler(x, sig, 5, 7)
+    assert n1.shape == x.shape and not torch.equal(n1, n2) and torch.equal(again(sig[0], sig[1]), n1)   # seeded
