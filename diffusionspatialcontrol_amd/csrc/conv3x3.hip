@@ -45,7 +45,8 @@ struct ConvParams {
     int B, H, W, Cin, Cout;
     int up;                       // 1: x is [B, H/2, W/2, Cin] and is read through a nearest-neighbour 2x upsampling
     int nchw;                     // 1: out is [B, Cout, H, W] (the UNet's conv_out: 4 channels back to the sampler's layout)
-    int sub2;                     // 1: only the even pixels are kept: out is [B, H/2, W/2, Cout] = the stride-2 convolution
+    int sub2;                     // 1 / 2: only the even / odd pixels are kept: out is [B, H/2, W/2, Cout] = the stride-2
+                                  // convolution with pad 1 (UNet Downsample2D) / with pad (0,1,0,1) (VAE encoder)
     long long onpix;              // output pixels (npix, or npix / 4 with sub2)
     long long ldx, ldr, ldo;      // pixel strides (elements)
     int nc, splits, cps;          // 64-channel slices, split count, slices per split
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
             const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
             long long gp = ((long long)b * p.H + yy) * p.W + xx;
             bool live = b >= 0 && n0 + ch * 8 + 8 <= p.Cout;
-            if (p.sub2) { live = live && !((yy | xx) & 1); gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1); }
+            if (p.sub2) { live = live && (p.sub2 == 1 ? !((yy | xx) & 1) : (yy & xx & 1) != 0); gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1); }
             if (live) rpre[cidx] = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + n0 + ch * 8);
         }
     }
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
         if (b < 0) continue;
         const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
         long long gp = ((long long)b * p.H + yy) * p.W + xx;
-        if (p.sub2) {                                                // stride 2 = the even pixels of the stride-1 result
-            if ((yy | xx) & 1) continue;
+        if (p.sub2) {                                                // stride 2 = the even (odd) pixels of the stride-1 result
+            if (p.sub2 == 1 ? ((yy | xx) & 1) != 0 : (yy & xx & 1) == 0) continue;
             gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1);
         }
         const float* sp_ = stage + m * kEpiStride + ch * 8;
@@ -497,9 +498,10 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     p.out = static_cast<half_t*>(out); p.ws = static_cast<float*>(workspace);
     p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.stamps = g_conv_stamps;
-    if (resample < 0 || resample > 2 || (resample == DSC_CONV_STRIDE2 && out_nchw)) return DSC_ERR_UNSUPPORTED;
+    if (resample < 0 || resample > 3 || ((resample == DSC_CONV_STRIDE2 || resample == DSC_CONV_STRIDE2_PAD_BR) && out_nchw)) return DSC_ERR_UNSUPPORTED;
+    if ((resample == DSC_CONV_STRIDE2 || resample == DSC_CONV_STRIDE2_PAD_BR) && ((H | W) & 1)) return DSC_ERR_UNSUPPORTED;
     p.up = resample == DSC_CONV_UPSAMPLE2X ? 1 : 0;
-    p.sub2 = resample == DSC_CONV_STRIDE2 ? 1 : 0;
+    p.sub2 = resample == DSC_CONV_STRIDE2 ? 1 : (resample == DSC_CONV_STRIDE2_PAD_BR ? 2 : 0);
     p.onpix = p.sub2 ? p.npix / 4 : p.npix;
     p.nchw = out_nchw ? 1 : 0;
     {

@@ -303,16 +303,291 @@ class StableDiffusionPipeline:
                                              num_inference_steps, sampler_opt, seed, start_time, timeout)
         return [self.latent_to_image(latents, output_type)]
 
+    def get_sampler_extra_args_i2i(self, sigmas, steps, sampler_opt, latents, seed, func):
+        """reference :916-941"""
+        params = inspect.signature(func).parameters
+        extra = {}
+        if "sigma_min" in params:
+            extra["sigma_min"] = sigmas[-2]              # the last sigma is zero, which DPM fast / adaptive do not allow
+        if "sigma_max" in params:
+            extra["sigma_max"] = sigmas[0]
+        if "n" in params:
+            extra["n"] = len(sigmas) - 1
+        if "sigma_sched" in params:
+            extra["sigma_sched"] = sigmas
+        if "sigmas" in params:
+            extra["sigmas"] = sigmas
+        if sampler_opt.get("brownian_noise", False):
+            extra["noise_sampler"] = self.create_noise_sampler(latents, sigmas, steps, seed)
+        if sampler_opt.get("solver_type", None) == "heun":
+            extra["solver_type"] = "heun"
+        return extra
+
+    # ---- image-side helpers of img2img / inpainting
+    def preprocess(self, image):
+        """reference :458-481 (`[-1, 1]` NCHW float tensor; PIL images are resized down to a multiple of 8, lanczos)"""
+        if isinstance(image, torch.Tensor):
+            return image
+        import numpy as np
+        import PIL.Image
+        if isinstance(image, PIL.Image.Image):
+            image = [image]
+        if isinstance(image[0], PIL.Image.Image):
+            w, h = image[0].size
+            w, h = (v - v % 8 for v in (w, h))
+            arr = np.concatenate([np.array(i.convert("RGB").resize((w, h), resample=PIL.Image.LANCZOS))[None] for i in image])
+            return torch.from_numpy(2.0 * (arr.astype(np.float32) / 255.0).transpose(0, 3, 1, 2) - 1.0)
+        return torch.cat(list(image), dim=0)
+
+    def _image_tensor(self, image, height, width, mask=False):
+        """What the reference's VaeImageProcessor.preprocess calls (:1447-1449, :1480-1482) amount to for tensors, numpy
+        arrays and PIL images: NCHW float32 at (height, width); images in [-1, 1], masks one channel binarised at 0.5"""
+        import numpy as np
+        if not isinstance(image, torch.Tensor):
+            import PIL.Image
+            if isinstance(image, PIL.Image.Image):
+                image = image.convert("L" if mask else "RGB").resize((width, height), resample=PIL.Image.LANCZOS)
+                image = np.array(image).astype(np.float32) / 255.0
+            arr = np.asarray(image, dtype=np.float32)             # numpy: HW, HWC or NCHW, values in [0, 1]
+            image = torch.from_numpy(arr)
+            if arr.ndim == 2:
+                image = image[None, None]
+            elif arr.ndim == 3:
+                image = image.permute(2, 0, 1)[None]
+            if not mask:
+                image = 2.0 * image - 1.0
+        image = image.float()
+        if image.ndim == 3:
+            image = image[None]
+        if mask:
+            if image.shape[1] != 1:
+                image = image.mean(dim=1, keepdim=True)
+            image = (image >= 0.5).float()
+        if tuple(image.shape[-2:]) != (height, width):
+            image = torch.nn.functional.interpolate(image, size=(height, width), mode="nearest" if mask else "bilinear")
+        return image
+
+    def _encode_vae_image(self, image, generator):
+        """reference :1234-1246: sample the posterior, times the scaling factor"""
+        if self.vae is None or not hasattr(self.vae, "encode"):
+            raise NotImplementedError("img2img / inpainting from pixels needs a VAE with an encoder "
+                                      "(modules.vae_decoder.AutoencoderKL); pass 4-channel latents instead")
+        image = image.to(self.vae.device, dtype=self.vae.dtype)
+        return self.vae.config.scaling_factor * self.vae.encode(image).latent_dist.sample(generator)
+
+    def _encode_text_rows(self, prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, text_input_ids,
+                          num_images_per_prompt, clip_skip, long_encode, device):
+        """(text rows [u.., c..] in the UNet dtype, token ids, number of images) - reference :1006-1023"""
+        cfg = self.do_classifier_free_guidance
+        if prompt_embeds is None:
+            if prompt is None or self.tokenizer is None or self.text_encoder is None:
+                raise NotImplementedError("pass prompt_embeds / negative_prompt_embeds / text_input_ids, or construct the "
+                                          "pipeline with a tokenizer and a CLIP text encoder and pass `prompt`")
+            from .encoder_prompt_modify import encode_prompt_function
+            prompt_embeds, negative_prompt_embeds, text_input_ids = encode_prompt_function(
+                self, prompt, device, 1, cfg, negative_prompt, clip_skip=clip_skip, long_encode=long_encode)
+        n_img = prompt_embeds.shape[0] * num_images_per_prompt
+        text = prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        if cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("classifier-free guidance needs negative_prompt_embeds")
+            text = torch.cat([negative_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0), text])
+        if text_input_ids is None:
+            text_input_ids = [None, None]
+        return text.to(device=device, dtype=self.unet.dtype), text_input_ids, n_img
+
+    @staticmethod
+    def _randn_like_ref(shape, generator, device, dtype):
+        """diffusers randn_tensor: drawn on the generator's device, moved to `device`"""
+        gdev = generator.device if generator is not None else device
+        return torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+
+    @torch.no_grad()
+    def img2img(self, prompt=None, num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None,
+                generator: Optional[torch.Generator] = None, image=None, output_type: Optional[str] = "pil", latents=None,
+                strength=1.0, region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
+                scale_ratio=8.0, latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), upscale=False,
+                width=None, height=None, seed=0, ip_adapter_image=None, control_img=None, image_t2i_adapter=None,
+                guidance_rescale: float = 0.0, cross_attention_kwargs=None, clip_skip=None, long_encode=0,
+                num_images_per_prompt=1, ip_adapter_image_embeds=None,
+                prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                text_input_ids=None, fused: Optional[bool] = None, **unsupported):
+        """reference :543-846: encode the image (or take `latents`), keep the last `strength` fraction of the schedule, add
+        noise, denoise.  Reproduces the reference's start: `latents + noise * sqrt(sigma_0^2 + 1)` (:647 - sic, not
+        `noise * sigma_0`)."""
+        if upscale or ip_adapter_image is not None or control_img is not None or image_t2i_adapter is not None \
+                or self.controlnet is not None or latent_processing:
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images / ControlNet / T2I-Adapter / latent "
+                                      "previews are outside the denoising hot path built here (SURVEY.md 8f)")
+        sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
+        device = self._execution_device
+        if image is not None:
+            image = self.preprocess(image)
+            latents = self._encode_vae_image(image, generator)                                       # :600-606
+        if latents is None:
+            raise ValueError("img2img needs `image` or `latents`")
+        if height is None:
+            height = int(latents.shape[-2]) * 8
+        if width is None:
+            width = int(latents.shape[-1]) * 8
+        latents = latents.to(device, dtype=self.unet.dtype)
+        self._do_classifier_free_guidance = guidance_scale > 1.0
+        text, text_input_ids, n_img = self._encode_text_rows(prompt, negative_prompt, prompt_embeds, negative_prompt_embeds,
+                                                             text_input_ids, num_images_per_prompt, clip_skip, long_encode,
+                                                             device)
+        if latents.shape[0] != n_img:
+            latents = latents.repeat(n_img // latents.shape[0], 1, 1, 1)
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)                # :637-638
+        t_start = max(num_inference_steps - init_timestep, 0)
+        sigmas = self.get_sigmas(num_inference_steps, sampler_opt).to(device, dtype=text.dtype)
+        sigma_sched = sigmas[t_start:]
+        noise = self._randn_like_ref(latents.shape, generator, device, text.dtype)
+        latents = latents + noise * (sigma_sched[0] ** 2 + 1) ** 0.5                                 # :647
+        region_state = encode_region_map(self, region_map_state, width=width, height=height,
+                                         num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)
+        cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
+        self._added_cond_kwargs = None
+        if ip_adapter_image_embeds is not None:
+            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt,
+                                                          self.do_classifier_free_guidance)
+            self._added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
+        if fused is None:
+            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and self.do_classifier_free_guidance
+        if fused:
+            latents = self._denoise_fused(latents, sigma_sched, text, region_state, weight_func, guidance_scale, n_img,
+                                          cross_attention_kwargs, start_time, timeout)
+        else:
+            args = self.get_sampler_extra_args_i2i(sigma_sched, len(sigma_sched), sampler_opt, latents, seed, sampler)
+            latents = self._denoise_protocol(sampler, latents, sigma_sched, text, region_state, weight_func, guidance_scale,
+                                             guidance_rescale, n_img, cross_attention_kwargs, 0.0, len(sigma_sched),
+                                             sampler_opt, seed, start_time, timeout, sampler_args=args)
+        return [self.latent_to_image(latents, output_type)]
+
+    def _sigma_to_alpha_sigma_t(self, sigma):
+        alpha_t = 1 / ((sigma ** 2 + 1) ** 0.5)                                                      # :1293-1297
+        return alpha_t, sigma * alpha_t
+
+    def add_noise(self, init_latents_proper, noise, sigma):
+        if isinstance(sigma, torch.Tensor) and sigma.numel() > 1:                                    # :1299-1304
+            sigma = sigma.sort(descending=True)[0][0].item()
+        return init_latents_proper + sigma * noise
+
+    def prepare_latents_inpating(self, batch_size, num_channels_latents, height, width, dtype, device, generator,
+                                 latents=None, image=None, sigma=None, is_strength_max=True, return_noise=False,
+                                 return_image_latents=False):
+        """reference :1306-1362 (same spelling)"""
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if (image is None or sigma is None) and not is_strength_max:
+            raise ValueError("Since strength < 1. initial latents are to be initialised as a combination of Image + Noise."
+                             "However, either the image or the noise sigma has not been provided.")
+        image_latents = None
+        if return_image_latents or (latents is None and not is_strength_max):
+            image = image.to(device=device, dtype=dtype)
+            image_latents = image if image.shape[1] == 4 else self._encode_vae_image(image, generator).to(device, dtype)
+            image_latents = image_latents.repeat(batch_size // image_latents.shape[0], 1, 1, 1)
+        if latents is None:
+            noise = self._randn_like_ref(shape, generator, device, dtype)
+            latents = noise if is_strength_max else self.add_noise(image_latents, noise, sigma)
+            latents = latents * (sigma.item() ** 2 + 1) ** 0.5 if is_strength_max else latents
+        else:
+            noise = latents.to(device)
+            latents = noise * (sigma.item() ** 2 + 1) ** 0.5
+        out = (latents,)
+        if return_noise:
+            out += (noise,)
+        if return_image_latents:
+            out += (image_latents,)
+        return out
+
+    @torch.no_grad()
+    def inpaiting(self, prompt=None, height: int = 512, width: int = 512, num_inference_steps: int = 50,
+                  guidance_scale: float = 7.5, negative_prompt=None, eta: float = 0.0,
+                  generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
+                  output_type: Optional[str] = "pil", callback_steps: Optional[int] = 1, upscale=False,
+                  region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
+                  latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), seed=0,
+                  ip_adapter_image=None, control_img=None, image_t2i_adapter=None, image=None, mask_image=None,
+                  masked_image_latents=None, padding_mask_crop=None, strength: float = 1.0, guidance_rescale: float = 0.0,
+                  cross_attention_kwargs=None, clip_skip=None, long_encode=0, num_images_per_prompt=1,
+                  ip_adapter_image_embeds=None,
+                  prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                  text_input_ids=None, **unsupported):
+        """reference :1365-1760 (method name as spelled there), the 4-channel UNet branch: the known region
+        `image_latents + sigma * noise` is re-imposed on the model input before every model call after the first
+        (:1599-1612).  Protocol mode only (the blend is a hook on the model input)."""
+        if upscale or ip_adapter_image is not None or control_img is not None or image_t2i_adapter is not None \
+                or self.controlnet is not None or latent_processing or padding_mask_crop is not None:
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images / ControlNet / T2I-Adapter / latent "
+                                      "previews / mask cropping are outside the denoising hot path built here")
+        if self.unet.config.in_channels != 4:
+            raise NotImplementedError("the 9-channel inpainting UNet (mask + masked-image latents concatenated to the "
+                                      "input) is a 'next' row: the few-channel conv_in kernel takes <= 8 input channels")
+        if image is None or mask_image is None:
+            raise ValueError("inpaiting needs `image` and `mask_image`")
+        sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
+        device = self._execution_device
+        self._do_classifier_free_guidance = guidance_scale > 1.0
+        text, text_input_ids, n_img = self._encode_text_rows(prompt, negative_prompt, prompt_embeds, negative_prompt_embeds,
+                                                             text_input_ids, num_images_per_prompt, clip_skip, long_encode,
+                                                             device)
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)                # :1432-1438
+        t_start = max(num_inference_steps - init_timestep, 0)
+        sigmas = self.get_sigmas(num_inference_steps, sampler_opt).to(device, dtype=text.dtype)
+        sigmas = sigmas[t_start:] if 0 <= strength < 1.0 else sigmas
+        is_strength_max = strength == 1.0
+        init_image = self._image_tensor(image, height, width) if not (isinstance(image, torch.Tensor) and image.shape[1] == 4) \
+            else image.float()
+        latents, noise_inp, image_latents = self.prepare_latents_inpating(
+            n_img, 4, height, width, text.dtype, device, generator, latents, image=init_image, sigma=sigmas[0],
+            is_strength_max=is_strength_max, return_noise=True, return_image_latents=True)           # :1459-1478
+        mask = self._image_tensor(mask_image, height, width, mask=True)
+        mask = torch.nn.functional.interpolate(mask, size=(height // self.vae_scale_factor, width // self.vae_scale_factor))
+        mask = mask.to(device=device, dtype=text.dtype)                                              # :1253-1257
+        if mask.shape[0] < n_img:
+            mask = mask.repeat(n_img // mask.shape[0], 1, 1, 1)
+        region_state = encode_region_map(self, region_map_state, width=width, height=height,
+                                         num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)
+        cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
+        self._added_cond_kwargs = None
+        if ip_adapter_image_embeds is not None:
+            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt,
+                                                          self.do_classifier_free_guidance)
+            self._added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
+        sig_last = float(sigmas[-1])
+
+        def keep_known_region(x, sigma, call_index):                                                 # :1599-1612
+            if call_index == 0:
+                return x
+            s = float(sigma[0])
+            known = image_latents
+            if s > sig_last:
+                alpha_t, sigma_t = self._sigma_to_alpha_sigma_t(s)
+                known = alpha_t * image_latents + sigma_t * noise_inp
+            rate = (s ** 2 + 1) ** 0.5
+            return ((1 - mask) * known + mask * x / rate) * rate
+
+        latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
+                                         guidance_rescale, n_img, cross_attention_kwargs, eta, num_inference_steps,
+                                         sampler_opt, seed, start_time, timeout, input_hook=keep_known_region)
+        return [self.latent_to_image(latents, output_type)]
+
     # ---- protocol mode: the reference's model_fn closure (:1091-1171) + sampler call (:1172-1175)
     def _denoise_protocol(self, sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                           guidance_rescale, n_img, cross_attention_kwargs, eta, steps, sampler_opt, seed, start_time,
-                          timeout):
+                          timeout, sampler_args=None, input_hook=None):
+        """sampler_args: the keyword arguments for `sampler` when the caller built them itself (img2img's
+        get_sampler_extra_args_i2i); input_hook(x, sigma, call_index) -> x: applied to the model input (inpainting's
+        re-imposition of the known region, reference :1599-1612)"""
         cfg = self.do_classifier_free_guidance
         kdm = self.k_diffusion_model
+        calls = [0]
 
         def model_fn(x, sigma):
             if start_time > 0 and timeout > 0:
                 assert (time.time() - start_time) < timeout, "inference process timed out"
+            if input_hook is not None:
+                x = input_hook(x, sigma, calls[0])
+            calls[0] += 1
             latent_model_input = torch.cat([x] * 2) if cfg else x
             cross_attention_kwargs["region_prompt"] = {
                 "region_state": region_state, "sigma": sigma[0], "weight_func": weight_func, "n_std_groups": n_img}
@@ -331,7 +606,8 @@ class StableDiffusionPipeline:
                     noise_pred = rescale_noise_cfg(noise_pred, c, guidance_rescale=guidance_rescale)
             return noise_pred
 
-        extra = self.get_sampler_extra_args_t2i(sigmas, eta, steps, sampler_opt, latents, seed, sampler)
+        extra = sampler_args if sampler_args is not None else \
+            self.get_sampler_extra_args_t2i(sigmas, eta, steps, sampler_opt, latents, seed, sampler)
         return sampler(model_fn, latents, **extra)
 
     # ---- fused mode

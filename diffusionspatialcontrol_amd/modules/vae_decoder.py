@@ -1,4 +1,5 @@
-"""VAE decoder (latents -> RGB) - the step right after the denoising loop, SURVEY.md 8f rank 1.
+"""VAE decoder (latents -> RGB) - the step right after the denoising loop, SURVEY.md 8f rank 1 - and encoder
+(RGB -> latent moments) - the step right before it in img2img / inpainting (reference model_k_diffusion.py:600-606,1234-1246).
 
 Counterpart of what reference `source/modules/model_k_diffusion.py` reaches through `self.vae.decode(latents)` in
 `decode_latents` (:291-299) / `latent_to_image` (:533-539): diffusers 0.27.2 `AutoencoderKL` (un-vendored), decoder half
@@ -156,3 +157,107 @@ class AutoencoderKLDecoder(nn.Module):
         else:
             x = d.conv_out(hn.contiguous()).contiguous()
         return type("DecoderOutput", (), {"sample": x})() if return_dict else (x,)
+
+
+# --------------------------------------------------------------------------------------------------- encoder half
+class _Down(nn.Module):
+    def __init__(self, cin, cout, n, groups, downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([VaeResnet(cin if i == 0 else cout, cout, groups) for i in range(n)])
+        if downsample:     # diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) then a stride-2 / pad-0 convolution
+            self.downsamplers = nn.ModuleList([nn.ModuleDict({"conv": nn.Conv2d(cout, cout, 3, stride=2, padding=0)})])
+
+
+class Encoder(nn.Module):
+    """diffusers 0.27.2 `Encoder` of AutoencoderKL (un-vendored; structure of the published SD1.x VAE): conv_in 3 -> 128,
+    four down blocks of 2 ResNets (128, 256, 512, 512; a stride-2 convolution after the first three), mid (ResNet,
+    single-head attention, ResNet), GroupNorm + SiLU, conv_out 512 -> 2 * latent_channels (mean | logvar)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        ch = list(cfg.block_out_channels)
+        self.conv_in = nn.Conv2d(cfg.out_channels, ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        prev = ch[0]
+        for i, c in enumerate(ch):
+            self.down_blocks.append(_Down(prev, c, cfg.layers_per_block, cfg.norm_num_groups, i < len(ch) - 1))
+            prev = c
+        self.mid_block = _Mid(ch[-1], cfg.norm_num_groups)
+        self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[-1], 1e-6, act=True)
+        self.conv_out = nn.Conv2d(ch[-1], 2 * cfg.latent_channels, 3, padding=1)
+
+
+class DiagonalGaussianDistribution:
+    """diffusers `DiagonalGaussianDistribution` (what `vae.encode(x).latent_dist` is): mean | logvar moments, logvar
+    clamped to [-30, 20]; `sample(generator)` draws on the generator's device like diffusers' randn_tensor."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator=None):
+        gdev = generator.device if generator is not None else self.mean.device
+        noise = torch.randn(self.mean.shape, generator=generator, device=gdev, dtype=self.mean.dtype).to(self.mean.device)
+        return self.mean + self.std * noise
+
+    def mode(self):
+        return self.mean
+
+
+class AutoencoderKL(AutoencoderKLDecoder):
+    """Both halves, diffusers key names (`encoder.*`, `quant_conv.*`, `decoder.*`, `post_quant_conv.*`): 83,653,863
+    parameters in the SD1.x configuration (the published AutoencoderKL total).  `encode(x).latent_dist` as the reference's
+    img2img (:603-606) and `_encode_vae_image` (:1234-1246) use it.  **Parity unpinned** (diffusers absent); oracle
+    restatement on shared weights: oracle/vae_ref.py `vae_encode`."""
+
+    def __init__(self, cfg: VaeConfig = None):
+        super().__init__(cfg)
+        cfg = self.cfg
+        self.config["latent_channels"] = cfg.latent_channels
+        self.encoder = Encoder(cfg)
+        self.quant_conv = Conv1x1(2 * cfg.latent_channels, 2 * cfg.latent_channels)
+
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    def encode(self, x, return_dict=True):
+        e = self.encoder
+        cl = torch.channels_last
+        x = x.to(self.dtype)
+        wt = _derived_w(e.conv_in, "fewcin", lambda w: w.reshape(w.shape[0], -1).t().contiguous())
+        if x.is_cuda and x.dtype == torch.float16 and x.shape[1] <= 8:
+            h = ops.conv3x3_fewcin(x, wt, e.conv_in.bias, e.conv_in.out_channels)          # NCHW image in, channels-last out
+        else:
+            h = e.conv_in(x).contiguous(memory_format=cl)
+        for blk in e.down_blocks:
+            for res in blk.resnets:
+                h = res(h)
+            if hasattr(blk, "downsamplers"):
+                conv = blk.downsamplers[0]["conv"]
+                wcl = _derived_w(conv, "cl", lambda w: w.contiguous(memory_format=cl))
+                if h.shape[-1] % 2 == 0 and h.shape[-2] % 2 == 0 and ops.conv3x3_supported(h, wcl):
+                    h = ops.conv3x3(h, wcl, conv.bias, stride2_pad_br=True)                # odd pixels of the stride-1 taps
+                else:
+                    h = F.conv2d(F.pad(h, (0, 1, 0, 1)), conv.weight, conv.bias, stride=2).contiguous(memory_format=cl)
+        h = e.mid_block.resnets[0](h)
+        h = e.mid_block.attentions[0](h)
+        h = e.mid_block.resnets[1](h)
+        hn = e.conv_norm_out(h)
+        wcl = _derived_w(e.conv_out, "cl", lambda w: w.contiguous(memory_format=cl))
+        if ops.conv3x3_supported(hn, wcl):
+            m = ops.conv3x3(hn, wcl, e.conv_out.bias, out_nchw=True)                        # 512 -> 8 channels, channel-major
+        else:
+            m = e.conv_out(hn).contiguous()
+        m = F.conv2d(m, self.quant_conv.weight, self.quant_conv.bias)                       # 8 x 8 1x1 on the moments
+        dist = DiagonalGaussianDistribution(m)
+        return type("AutoencoderKLOutput", (), {"latent_dist": dist})() if return_dict else (dist,)
+
+
+def _derived_w(conv, key, build):
+    """weight of `conv` in another layout, cached on the module and rebuilt when the parameter changes"""
+    from .u_net_condition_modify import _derived
+    return _derived(conv, "w_" + key, (conv.weight,), lambda: build(conv.weight))

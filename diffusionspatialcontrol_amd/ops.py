@@ -391,13 +391,14 @@ def conv3x3_supported(x, weight, upsample=False):
     return bool(_lib.load_library().dsc_conv3x3_supported(B, H * f, W * f, C, weight.shape[0]))
 
 
-def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_nchw=False, stride2=False):
+def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_nchw=False, stride2=False, stride2_pad_br=False):
     """3x3 / stride 1 / pad 1 convolution (+ bias) (+ residual) of a channels_last fp16 [B, Cin, H, W] tensor with a
     [Cout, Cin, 3, 3] weight held in channels_last memory format (dsc_conv3x3_nhwc_f16); returns channels_last
     [B, Cout, H, W], or a plain contiguous (NCHW) tensor with out_nchw=True.  upsample=True convolves the 2x
     nearest-neighbour upsampling of x (output [B, Cout, 2H, 2W]) without materialising it; stride2=True is the
-    stride-2 / pad-1 convolution (output [B, Cout, H/2, W/2], H and W even).  Raises on an unsupported shape - ask
-    conv3x3_supported() first."""
+    stride-2 / pad-1 convolution (output [B, Cout, H/2, W/2], H and W even); stride2_pad_br=True the stride-2 convolution with
+    zero padding on the bottom / right only (`F.pad(x, (0, 1, 0, 1))` + stride-2 / pad-0 conv: AutoencoderKL encoder).  Raises
+    on an unsupported shape - ask conv3x3_supported() first."""
     _require_gpu(x, weight)
     lib = _lib.load_library()
     cl = torch.channels_last
@@ -409,9 +410,9 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_n
     if upsample:
         H, W = 2 * H, 2 * W
     Cout = weight.shape[0]
-    if upsample and stride2:
-        raise ValueError("conv3x3: upsample and stride2 exclude each other")
-    oh, ow = (H // 2, W // 2) if stride2 else (H, W)
+    if int(bool(upsample)) + int(bool(stride2)) + int(bool(stride2_pad_br)) > 1:
+        raise ValueError("conv3x3: upsample, stride2 and stride2_pad_br exclude each other")
+    oh, ow = (H // 2, W // 2) if (stride2 or stride2_pad_br) else (H, W)
     if out_nchw:
         out = torch.empty((B, Cout, oh, ow), dtype=x.dtype, device=x.device)
     else:
@@ -426,7 +427,7 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_n
     nbytes = lib.dsc_conv3x3_workspace_bytes(B, H, W, Cin, Cout, splits)
     ws = _workspace(x.device, nbytes) if nbytes else None
     rc = lib.dsc_conv3x3_nhwc_f16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, Cin, ldr, Cout,
-                                  2 if stride2 else (1 if upsample else 0), 1 if out_nchw else 0, splits, 0, _p(ws),
+                                  3 if stride2_pad_br else (2 if stride2 else (1 if upsample else 0)), 1 if out_nchw else 0, splits, 0, _p(ws),
                                   ws.numel() * 8 if ws is not None else 0, _stream_ptr(x))
     _lib.check(rc, "dsc_conv3x3_nhwc_f16")
     return out

@@ -235,6 +235,8 @@ int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* r
  */
 #define DSC_CONV_UPSAMPLE2X 1
 #define DSC_CONV_STRIDE2 2
+#define DSC_CONV_STRIDE2_PAD_BR 3   /* stride 2 with zero padding on the bottom / right only (F.pad (0,1,0,1) + stride-2 conv of
+                                     * the AutoencoderKL encoder's Downsample2D): the ODD pixels of the stride-1 / pad-1 taps */
 int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
 /* diagnostics: 8 x int64 per workgroup (start / loop start / loop end / end in 100 MHz ticks, the three segment lengths in
  * shader clocks, XCC and HW ids) of every following dsc_conv3x3_nhwc_f16 call go to `device_buffer`; NULL switches it off */

@@ -125,7 +125,7 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
 
 
 def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None,
-                 sampler=None, sampler_kwargs=None):
+                 sampler=None, sampler_kwargs=None, input_hook=None):
     """txt2img's loop for n_img images in the row layout [u_0.., c_0..]; returns the final latents (fp32).
 
     latents: initial noise ALREADY multiplied by sqrt(sigma_0^2 + 1) (model_k_diffusion.py:1043);
@@ -136,7 +136,12 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
     if steps_limit is not None:
         sig = sig[:steps_limit + 1]
 
+    calls = [0]
+
     def model_fn(x, sigma):
+        if input_hook is not None:                     # inpainting: the known region re-imposed on the model input (:1599-1612)
+            x = input_hook(x, sigma, calls[0])
+        calls[0] += 1
         inp = torch.cat([x] * 2)                                                      # :1097
         rp = {"region_state": region_state, "sigma": float(sigma[0]), "weight_func": ra.default_weight_func}
 

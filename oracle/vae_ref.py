@@ -56,3 +56,40 @@ def decode_latents(sd, latents, scaling_factor=0.18215, groups=32):
     """model_k_diffusion.py:291-299"""
     image = vae_decode(sd, latents.float() / scaling_factor, groups)
     return (image / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).numpy()
+
+
+def vae_encode_moments(sd, x, groups=32):
+    """diffusers 0.27.2 `AutoencoderKL.encode` up to the moments (mean | logvar) tensor (un-vendored, restated from the
+    published SD1.x VAE encoder: parity unpinned; reached from reference model_k_diffusion.py:603-606,1234-1246).  The
+    down-sampling convolutions pad bottom / right only (`F.pad(x, (0, 1, 0, 1))`, stride 2, no padding)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    h = _c(sd, "encoder.conv_in", x.float())
+    i = 0
+    while f"encoder.down_blocks.{i}.resnets.0.norm1.weight" in sd:
+        j = 0
+        while f"encoder.down_blocks.{i}.resnets.{j}.norm1.weight" in sd:
+            h = _res(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, groups)
+            j += 1
+        pre = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+        if pre + ".weight" in sd:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[pre + ".weight"], sd[pre + ".bias"], stride=2)
+        i += 1
+    h = _res(sd, "encoder.mid_block.resnets.0", h, groups)
+    b, c, hh, ww = h.shape
+    t = _gn(sd, "encoder.mid_block.attentions.0.group_norm", h, groups).reshape(b, c, hh * ww).transpose(1, 2)
+    p = "encoder.mid_block.attentions.0."
+    q = F.linear(t, sd[p + "to_q.weight"], sd[p + "to_q.bias"])
+    k = F.linear(t, sd[p + "to_k.weight"], sd[p + "to_k.bias"])
+    v = F.linear(t, sd[p + "to_v.weight"], sd[p + "to_v.bias"])
+    o = torch.softmax(q @ k.transpose(1, 2) / (c ** 0.5), dim=-1) @ v
+    o = F.linear(o, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+    h = h + o.transpose(1, 2).reshape(b, c, hh, ww)
+    h = _res(sd, "encoder.mid_block.resnets.1", h, groups)
+    h = _c(sd, "encoder.conv_out", F.silu(_gn(sd, "encoder.conv_norm_out", h, groups)))
+    return _c(sd, "quant_conv", h, padding=0)
+
+
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution.sample with the noise given: mean + exp(0.5 clamp(logvar, -30, 20)) * noise"""
+    mean, logvar = moments.chunk(2, dim=1)
+    return mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise

@@ -371,3 +371,44 @@ def test_pipeline_sampler_plumbing():
     n1, n2 = ex["noise_sampler"](sig[0], sig[1]), ex["noise_sampler"](sig[1], sig[2])
     again = pipe.create_noise_sampler(x, sig, 5, 7)
     assert n1.shape == x.shape and not torch.equal(n1, n2) and torch.equal(again(sig[0], sig[1]), n1)   # seeded
+
+
+def test_vae_structure_and_image_side_helpers():
+    """AutoencoderKL: the published SD1.x parameter total, diffusers key names; the image-side helpers of img2img /
+    inpainting (reference model_k_diffusion.py:458-481, 916-941, 1293-1362) on CPU tensors"""
+    from diffusionspatialcontrol_amd.modules.vae_decoder import AutoencoderKL, DiagonalGaussianDistribution
+    with torch.device("meta"):
+        vae = AutoencoderKL()
+    assert sum(p.numel() for p in vae.parameters()) == 83653863
+    assert sum(p.numel() for p in vae.encoder.parameters()) == 34163592
+    keys = set(vae.state_dict().keys())
+    assert {"encoder.conv_in.weight", "encoder.down_blocks.2.downsamplers.0.conv.weight", "encoder.mid_block.attentions.0.to_q.weight",
+            "encoder.conv_norm_out.weight", "encoder.conv_out.bias", "quant_conv.weight", "post_quant_conv.bias"} <= keys
+    assert "encoder.down_blocks.3.downsamplers.0.conv.weight" not in keys
+    d = DiagonalGaussianDistribution(torch.cat([torch.ones(1, 4, 2, 2), torch.full((1, 4, 2, 2), 50.0)], dim=1))
+    assert float(d.logvar.max()) == 20.0 and torch.equal(d.mode(), torch.ones(1, 4, 2, 2))
+    s1, s2 = d.sample(torch.Generator().manual_seed(1)), d.sample(torch.Generator().manual_seed(1))
+    assert torch.equal(s1, s2)
+    unet = UNet2DConditionModel(UNetConfig.tiny()).half()
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    sig = pipe.get_sigmas(6, {"scheduler": "karras"})
+    ex = pipe.get_sampler_extra_args_i2i(sig[2:], 5, {}, torch.zeros(1, 4, 8, 8), 0, sampling.sample_dpmpp_2m)
+    assert set(ex) == {"sigmas"} and ex["sigmas"].shape == (5,)
+    a, st = pipe._sigma_to_alpha_sigma_t(3.0)
+    assert abs(a - 10 ** -0.5) < 1e-12 and abs(st - 3 * 10 ** -0.5) < 1e-12
+    lat = torch.ones(1, 4, 8, 8)
+    out = pipe.prepare_latents_inpating(1, 4, 64, 64, torch.float32, "cpu", None, latents=lat, image=lat * 2,
+                                        sigma=torch.tensor(2.0), is_strength_max=True, return_noise=True, return_image_latents=True)
+    assert torch.allclose(out[0], lat * 5 ** 0.5) and torch.equal(out[1], lat) and torch.equal(out[2], lat * 2)
+    g = torch.Generator().manual_seed(3)
+    out = pipe.prepare_latents_inpating(1, 4, 64, 64, torch.float32, "cpu", g, image=lat * 2, sigma=torch.tensor(2.0),
+                                        is_strength_max=False, return_noise=True, return_image_latents=True)
+    assert torch.allclose(out[0], lat * 2 + 2.0 * out[1])                       # image + sigma * noise, no extra scaling
+    with pytest.raises(ValueError):
+        pipe.prepare_latents_inpating(1, 4, 64, 64, torch.float32, "cpu", None, is_strength_max=False)
+    m = pipe._image_tensor(np.array([[0.2, 0.7], [0.5, 0.4]], dtype=np.float32), 4, 4, mask=True)
+    assert m.shape == (1, 1, 4, 4) and m[0, 0, 0, 3] == 1.0 and m[0, 0, 0, 0] == 0.0 and m[0, 0, 3, 0] == 1.0
+    im = pipe._image_tensor(np.zeros((4, 4, 3), dtype=np.float32), 4, 4)
+    assert im.shape == (1, 3, 4, 4) and float(im.max()) == -1.0
+    with pytest.raises(NotImplementedError):
+        pipe._encode_vae_image(torch.zeros(1, 3, 8, 8), None)

@@ -744,6 +744,107 @@ def test_vae_decoder_full_size(ops):
     assert y.shape == (1, 3, 512, 512) and torch.isfinite(y).all()
 
 
+@pytest.mark.parametrize("full", [False, True])
+def test_vae_encoder_matches_oracle(ops, full):
+    """VAE encode (img2img / inpainting front end): product (few-channel conv_in kernel, stride-2 convolutions as the odd
+    pixels of the stride-1 taps, HIP GroupNorm) vs the fp32 oracle restatement on shared weights - toy width (library
+    convolutions) and the SD1.x geometry (hand-written kernels) at 256x256."""
+    from diffusionspatialcontrol_amd.modules.vae_decoder import AutoencoderKL, VaeConfig
+    from oracle import vae_ref
+    torch.manual_seed(3)
+    cfg = VaeConfig() if full else VaeConfig.tiny()
+    vae = AutoencoderKL(cfg).half()
+    sd = {k: v.clone() for k, v in vae.state_dict().items()}
+    vae = vae.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    hw = 256 if full else 64
+    x = (torch.rand(2, 3, hw, hw, generator=g) * 2 - 1).half()
+    with torch.no_grad():
+        ref = vae_ref.vae_encode_moments(sd, x.float(), groups=cfg.norm_num_groups)
+        dist = vae.encode(x.cuda()).latent_dist
+    out = dist.parameters.float().cpu()
+    assert out.shape == (2, 8, hw // 8, hw // 8)
+    scale = ref.abs().max().item()
+    assert (out - ref).abs().max().item() < 2e-2 * scale and (out - ref).abs().mean().item() < 3e-3 * scale, \
+        ((out - ref).abs().max().item(), scale)
+    gen = torch.Generator().manual_seed(9)
+    smp = dist.sample(gen).float().cpu()
+    noise = torch.randn(2, 4, hw // 8, hw // 8, generator=torch.Generator().manual_seed(9), dtype=torch.float16).float()
+    assert (smp - vae_ref.gaussian_sample(out, noise)).abs().max().item() < 2e-3 * max(1.0, smp.abs().max().item())
+    assert torch.equal(dist.mode(), dist.mean)
+
+
+def test_conv3x3_stride2_pad_bottom_right(ops):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 128, 32, 48, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(192, 128, 3, 3, generator=g) / 34).half().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(192, generator=g).half().cuda()
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    for splits in (0, 2):
+        y = ops.conv3x3(x, w, b, stride2_pad_br=True, splits=splits)
+        assert y.shape == ref.shape
+        assert (y.float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+
+
+def test_img2img_and_inpainting_pipeline(ops):
+    """img2img (reference :543-846) and the 4-channel inpainting branch (:1365-1760) on the tiny UNet + tiny VAE: fused ==
+    protocol ~= the fp32 CPU oracle loop started from the same noised latents; the inpainting hook keeps the known region."""
+    from diffusionspatialcontrol_amd.modules import sampling
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    from diffusionspatialcontrol_amd.modules.vae_decoder import AutoencoderKL, VaeConfig
+    cfg, unet, sd, text = _tiny_setup(1)
+    state, ids, rs = _region_state(n_img=1)
+    torch.manual_seed(12)
+    vae = AutoencoderKL(VaeConfig.tiny()).half().cuda().eval()
+    pipe = StableDiffusionPipeline(vae, None, FakeTokenizer(), unet, SD15Scheduler())
+    steps, strength = 8, 0.6
+    lat0 = (torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(21)) * 0.8).half()
+    common = dict(num_inference_steps=steps, guidance_scale=7.5, output_type="latent", region_map_state=state,
+                  sampler_name="sample_dpmpp_2m", sampler_opt={"scheduler": "karras"}, prompt_embeds=text[1:2],
+                  negative_prompt_embeds=text[:1], text_input_ids=ids, width=128, height=128)
+    outs = {}
+    for fused in (True, False):
+        gen = torch.Generator().manual_seed(33)
+        outs[fused] = pipe.img2img(None, latents=lat0.clone(), strength=strength, generator=gen, fused=fused, **common)[0].float().cpu()
+    sig = pipe.get_sigmas(steps, {"scheduler": "karras"}).half().float().cpu()
+    t_start = steps - min(int(steps * strength), steps)
+    sched = sig[t_start:]
+    assert len(sched) == int(steps * strength) + 1
+    noise = torch.randn(lat0.shape, generator=torch.Generator().manual_seed(33), dtype=torch.float16)
+    start = (lat0 + noise * (sched[0].half() ** 2 + 1) ** 0.5).float()                 # the reference's start (:647)
+    ref = unet_ref.denoise_loop(sd, cfg, start, sched.tolist(), text.float(), rs, 7.5)
+    scale = ref.abs().max().item()
+    assert (outs[True] - outs[False]).abs().max().item() < 2e-2 * scale
+    assert (outs[True] - ref).abs().max().item() < 4e-2 * scale and (outs[True] - ref).abs().mean().item() < 6e-3 * scale
+    # from pixels: the VAE encoder path runs and strength = 1 keeps the whole schedule
+    img = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(2)) * 2 - 1
+    px = pipe.img2img(None, image=img, strength=1.0, generator=torch.Generator().manual_seed(1), **common)[0]
+    assert px.shape == (1, 4, 16, 16) and torch.isfinite(px).all()
+    # inpainting: left half known, right half repainted; Euler sampler so that the oracle can run the same sampler
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[..., 64:] = 1.0
+    common.pop("sampler_name")
+    gen = torch.Generator().manual_seed(44)
+    inp = pipe.inpaiting(None, image=lat0.clone(), mask_image=mask, strength=1.0, generator=gen,
+                         sampler_name="sample_euler", **common)[0].float().cpu()
+    n = torch.randn(lat0.shape, generator=torch.Generator().manual_seed(44), dtype=torch.float16).float()
+    m16 = F.interpolate(mask, size=(16, 16))
+    img_lat = lat0.float()
+
+    def hook(x, sigma, k):
+        if k == 0:
+            return x
+        s = float(sigma[0])
+        known = img_lat + s * n if s > 0 else img_lat
+        return (1 - m16) * known + m16 * x
+    ref_i = unet_ref.denoise_loop(sd, cfg, n * math.sqrt(float(sig[0]) ** 2 + 1), sig.tolist(), text.float(), rs, 7.5,
+                                  sampler=sampling.sample_euler, input_hook=hook)
+    sc = ref_i.abs().max().item()
+    assert (inp - ref_i).abs().max().item() < 4e-2 * sc, ((inp - ref_i).abs().max().item(), sc)
+    with pytest.raises(NotImplementedError):
+        pipe.inpaiting(None, image=lat0, mask_image=mask, padding_mask_crop=8, **common)
+
+
 def test_ip_adapter_unet_and_pipeline(ops):
     """IP-Adapter weights load into the UNet with the published key numbering (cross-attention
     layers numbered 1, 3, 5, ... over down_blocks, up_blocks, mid_block), the image tokens reach every cross-attention
