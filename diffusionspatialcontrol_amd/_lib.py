@@ -84,6 +84,11 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: its wheel carries its own libamdhip64 / libhipblaslt (same SONAMEs as /opt/rocm's).  Whichever copy is
+    # loaded first serves the whole process; if this library pulled in /opt/rocm's before torch initialised, torch's
+    # streams and this library's launches would sit on a runtime torch was not built against (observed: every launch
+    # fails with hipErrorInvalidResourceHandle-class errors).  The streams handed to the C ABI are torch's.
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise DscLibraryError(

@@ -528,16 +528,16 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     int ring = g_conv_ring;
     if (ring != 3 && ring != 9) ring = 3;
     if (tw == 16) {
-        if (ring == 9) hipLaunchKernelGGL((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
-        else hipLaunchKernelGGL((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);
+        if (ring == 9) DSC_LAUNCH((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
+        else DSC_LAUNCH((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);
     } else {
-        if (ring == 9) hipLaunchKernelGGL((conv3x3_kernel<8, 9>), grid, block, (size_t)lds_bytes(9), st, p);
-        else hipLaunchKernelGGL((conv3x3_kernel<8, 3>), grid, block, (size_t)lds_bytes(3), st, p);
+        if (ring == 9) DSC_LAUNCH((conv3x3_kernel<8, 9>), grid, block, (size_t)lds_bytes(9), st, p);
+        else DSC_LAUNCH((conv3x3_kernel<8, 3>), grid, block, (size_t)lds_bytes(3), st, p);
     }
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     if (p.splits > 1) {
         const long long n = p.onpix * (Cout / 8);
-        hipLaunchKernelGGL(conv3x3_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+        DSC_LAUNCH(conv3x3_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     }
     return DSC_OK;

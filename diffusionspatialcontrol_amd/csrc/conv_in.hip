@@ -62,7 +62,7 @@ extern "C" int dsc_conv3x3_fewcin_f16(const void* x_nchw, const void* w_t, const
         (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
         return DSC_ERR_UNSUPPORTED;
     const int threads = (Cout / 8) * kPix;
-    hipLaunchKernelGGL(conv_fewcin_kernel, dim3((unsigned)((long long)B * H * (W / kPix))), dim3(threads), 0,
+    DSC_LAUNCH(conv_fewcin_kernel, dim3((unsigned)((long long)B * H * (W / kPix))), dim3(threads), 0,
                        static_cast<hipStream_t>(stream), static_cast<const half_t*>(x_nchw), static_cast<const half_t*>(w_t),
                        static_cast<const half_t*>(bias), static_cast<half_t*>(out_nhwc), B, Cin, H, W, Cout);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;

@@ -19,6 +19,11 @@ __device__ __forceinline__ f16x_t mfma_32x32x16(h8_t a, h8_t b, f16x_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// Kernel launch whose status is THIS launch's: hipGetLastError() is sticky per thread, and other libraries in the process
+// leave benign errors behind (hipBLASLt probing for kernel names: hipErrorNotFound), which the entry points' post-launch
+// check would otherwise report as a failed launch
+#define DSC_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 __device__ __forceinline__ float round_f16(float x) { return (float)(half_t)x; }
 
 // SiLU x / (1 + e^-x) on v_exp_f32 + v_rcp_f32 (relative error ~2e-7) instead of the IEEE division sequence

@@ -295,7 +295,7 @@ extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias,
     // MFMA peak; the dispatch in ops.linear therefore sends long-K shapes to hipBLASLt's larger macro-tiles.
     const size_t lds = (size_t)3 * kStage * sizeof(half_t);          // the fp32 epilogue stage (34 KiB) reuses it
     const dim3 grid(mb * nb), block(T);
-    if (geglu) hipLaunchKernelGGL((gemm_tn_f16<true, 3>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
+    if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3>), grid, block, lds, st, p);
+    else DSC_LAUNCH((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -183,14 +183,14 @@ extern "C" int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, con
         const long long n = (long long)p.cpg * hw;
         p.nsplit = 1;
         const dim3 grid(B * groups), block(kT);
-        hipLaunchKernelGGL(gn_stats_scalar, grid, block, 0, st, p, n, n);
-        hipLaunchKernelGGL(gn_apply_scalar, grid, block, 0, st, p, n, n);
+        DSC_LAUNCH(gn_stats_scalar, grid, block, 0, st, p, n, n);
+        DSC_LAUNCH(gn_apply_scalar, grid, block, 0, st, p, n, n);
         return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
     }
     plan(p, B);
     const dim3 grid(B * groups * p.nsplit), block(kT);
-    hipLaunchKernelGGL(gn_stats, grid, block, 0, st, p);
-    hipLaunchKernelGGL(gn_apply, grid, block, 0, st, p);
+    DSC_LAUNCH(gn_stats, grid, block, 0, st, p);
+    DSC_LAUNCH(gn_apply, grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
@@ -200,7 +200,7 @@ extern "C" int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype,
     const long long total = rows * (n / 8);
     long long g = (total + kT - 1) / kT;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(geglu_kernel, dim3((int)g), dim3(kT), 0, static_cast<hipStream_t>(stream),
+    DSC_LAUNCH(geglu_kernel, dim3((int)g), dim3(kT), 0, static_cast<hipStream_t>(stream),
                        static_cast<const half_t*>(x), static_cast<half_t*>(y), (long long)rows, n / 8);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -419,7 +419,7 @@ extern "C" int dsc_add_bias_residual(const void* a, const void* b, const void* b
     const long long n8 = rows * (C / 8);
     long long g = (n8 + 255) / 256;
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(add_bias_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
+    DSC_LAUNCH(add_bias_kernel, dim3((int)g), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const half_t*>(a), static_cast<const half_t*>(b), static_cast<const half_t*>(bias),
                        static_cast<half_t*>(out), n8, C / 8);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
@@ -455,7 +455,7 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     p.eps = eps; p.silu = apply_silu;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p.cpg % 8 == 0 && (long long)p.HW * (p.cpg / 8) <= 256 * kSmallVec && g_gn_mode != 2) {      // small image: single launch
-        hipLaunchKernelGGL(gn_nhwc_small, dim3(B * groups), dim3(256), 0, st, p);
+        DSC_LAUNCH(gn_nhwc_small, dim3(B * groups), dim3(256), 0, st, p);
         return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
     }
     {
@@ -463,11 +463,11 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
         // tools/mb_gn.py: 1280 vectors 9.8 us vs 11.9 us for three launches; 3840 vectors 17.9 vs 12.6)
         GnBundle q{};
         if (g_gn_mode < 2 && bundle_plan(p, 256, 16, &q) && (long long)p.HW * q.nvec <= 1536) {
-            hipLaunchKernelGGL((gn_nhwc_bundle<256, 16>), dim3(B * (groups / q.gb)), dim3(256), (size_t)256 * 8 * sizeof(float), st, p, q);
+            DSC_LAUNCH((gn_nhwc_bundle<256, 16>), dim3(B * (groups / q.gb)), dim3(256), (size_t)256 * 8 * sizeof(float), st, p, q);
             return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
         }
         if (g_gn_mode == 3 && bundle_plan(p, 1024, 16, &q)) {       // diagnostics only: slower than three launches
-            hipLaunchKernelGGL((gn_nhwc_bundle<1024, 16>), dim3(B * (groups / q.gb)), dim3(1024), (size_t)1024 * 8 * sizeof(float), st, p, q);
+            DSC_LAUNCH((gn_nhwc_bundle<1024, 16>), dim3(B * (groups / q.gb)), dim3(1024), (size_t)1024 * 8 * sizeof(float), st, p, q);
             return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
         }
     }
@@ -480,8 +480,8 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_nhwc_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     }
-    hipLaunchKernelGGL(gn_nhwc_stats, dim3(B * p.nchunk), block, stats_lds, st, p);
-    if (!p.inline_stats) hipLaunchKernelGGL(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
-    hipLaunchKernelGGL(gn_nhwc_apply, dim3(B * p.anchunk), block, 0, st, p);
+    DSC_LAUNCH(gn_nhwc_stats, dim3(B * p.nchunk), block, stats_lds, st, p);
+    if (!p.inline_stats) DSC_LAUNCH(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
+    DSC_LAUNCH(gn_nhwc_apply, dim3(B * p.anchunk), block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -79,11 +79,11 @@ extern "C" int dsc_add_layernorm(const void* x, const void* a, const void* gamma
     const half_t* gp = static_cast<const half_t*>(gamma); const half_t* bp = static_cast<const half_t*>(beta);
     half_t* sp = static_cast<half_t*>(sum_out); half_t* yp = static_cast<half_t*>(y);
     switch (nv) {
-        case 1: hipLaunchKernelGGL(add_ln_kernel<1>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
-        case 2: hipLaunchKernelGGL(add_ln_kernel<2>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
-        case 3: hipLaunchKernelGGL(add_ln_kernel<3>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
-        case 4: hipLaunchKernelGGL(add_ln_kernel<4>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
-        default: hipLaunchKernelGGL(add_ln_kernel<kMaxV>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
+        case 1: DSC_LAUNCH(add_ln_kernel<1>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
+        case 2: DSC_LAUNCH(add_ln_kernel<2>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
+        case 3: DSC_LAUNCH(add_ln_kernel<3>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
+        case 4: DSC_LAUNCH(add_ln_kernel<4>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
+        default: DSC_LAUNCH(add_ln_kernel<kMaxV>, grid, block, 0, st, xp, ap, gp, bp, sp, yp, (long long)rows, C, eps); break;
     }
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

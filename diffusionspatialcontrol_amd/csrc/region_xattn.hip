@@ -272,7 +272,7 @@ void plan(XattnParams& p) { plan_tiles(p); }
 template <int NK, bool REF16>
 int launch_stats(const XattnParams& p, hipStream_t st) {
     const dim3 grid = xattn_grid(p), block(kThreads);
-    hipLaunchKernelGGL((xattn_stats<NK, REF16>), grid, block, stats_lds_bytes<NK>(), st, p);
+    DSC_LAUNCH((xattn_stats<NK, REF16>), grid, block, stats_lds_bytes<NK>(), st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 template <int NK, bool REF16>
@@ -285,7 +285,7 @@ int launch_fwd(const XattnParams& p, hipStream_t st) {
         attr_set = true;
     }
     const dim3 grid = xattn_grid(p), block(kThreads);
-    hipLaunchKernelGGL((xattn_fwd<NK, REF16>), grid, block, lds, st, p);
+    DSC_LAUNCH((xattn_fwd<NK, REF16>), grid, block, lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
@@ -400,7 +400,7 @@ extern "C" int dsc_region_xattn_std(const void* q, const void* k, int Bc, int H,
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = dispatch_stats(nk, ref16, p, st);
     if (rc != DSC_OK) return rc;
-    if (ref16) hipLaunchKernelGGL(xattn_std_finalize<true>, dim3(n_std_groups), dim3(kThreads), 0, st, p);
-    else hipLaunchKernelGGL(xattn_std_finalize<false>, dim3(n_std_groups), dim3(kThreads), 0, st, p);
+    if (ref16) DSC_LAUNCH(xattn_std_finalize<true>, dim3(n_std_groups), dim3(kThreads), 0, st, p);
+    else DSC_LAUNCH(xattn_std_finalize<false>, dim3(n_std_groups), dim3(kThreads), 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -298,7 +298,7 @@ size_t img_bytes_nk(int nk) {
 template <int NK>
 int launch_pack(const half_t* k, const half_t* v, half_t* img, int Bc, int H, int S, int d, const int64_t* ks,
                 const int64_t* vs, hipStream_t st) {
-    hipLaunchKernelGGL(xp_pack<NK>, dim3(Bc * H), dim3(256), 0, st, k, v, img, H, S, d, (long long)ks[0], (long long)ks[1],
+    DSC_LAUNCH(xp_pack<NK>, dim3(Bc * H), dim3(256), 0, st, k, v, img, H, S, d, (long long)ks[0], (long long)ks[1],
                        (long long)ks[2], (long long)vs[0], (long long)vs[1], (long long)vs[2]);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
@@ -316,9 +316,9 @@ int launch_packed(const XpParams& pp, bool need_stats, hipStream_t st) {
         attr_set = true;
     }
     if (need_stats)
-        hipLaunchKernelGGL((xp_stats<NK, REF16>), grid, block, (size_t)P::KFR * 1024 + kRedBytes, st, pp);
+        DSC_LAUNCH((xp_stats<NK, REF16>), grid, block, (size_t)P::KFR * 1024 + kRedBytes, st, pp);
     const size_t lds = (size_t)P::IMG * 2 + (size_t)kNUMax * kBP * 4 + kRedBytes;
-    hipLaunchKernelGGL((xp_fwd<NK, REF16>), grid, block, lds, st, pp);
+    DSC_LAUNCH((xp_fwd<NK, REF16>), grid, block, lds, st, pp);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 

@@ -94,7 +94,7 @@ extern "C" int dsc_prepare_unet_input(const void* x, float c_in, float t, float 
     if (!x || !x_in || !t_buf || !sigma_buf || n_img <= 0 || chw <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16 || chw % 8 != 0 || !al16(x) || !al16(x_in)) return DSC_ERR_UNSUPPORTED;
     const long long n8 = (long long)n_img * chw / 8;
-    hipLaunchKernelGGL(prepare_kernel, dim3(grid_for(n8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    DSC_LAUNCH(prepare_kernel, dim3(grid_for(n8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const half_t*>(x), c_in, t, sigma, static_cast<half_t*>(x_in), t_buf, sigma_buf,
                        n_img, chw);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
@@ -106,7 +106,7 @@ extern "C" int dsc_cfg_dpmpp2m_step(void* x, const void* eps, void* old, float s
     if (!x || !eps || !old || !x_in || !t_buf || !sigma_buf || n_img <= 0 || chw <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16 || chw % 8 != 0 || !al16(x) || !al16(eps) || !al16(old) || !al16(x_in)) return DSC_ERR_UNSUPPORTED;
     const long long n8 = (long long)n_img * chw / 8;
-    hipLaunchKernelGGL(step_kernel, dim3(grid_for(n8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    DSC_LAUNCH(step_kernel, dim3(grid_for(n8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<half_t*>(x), static_cast<const half_t*>(eps), static_cast<half_t*>(old), sigma,
                        guidance, a, b, c, c_in_next, t_next, sigma_next, static_cast<half_t*>(x_in), t_buf, sigma_buf,
                        n_img, chw);
@@ -118,7 +118,7 @@ extern "C" int dsc_dpmpp2m_update(const void* x, const void* denoised, const voi
     if (!x || !denoised || !out || n <= 0 || (!old && c != 0.f)) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16 || n % 8 != 0 || !al16(x) || !al16(denoised) || !al16(out) || (old && !al16(old)))
         return DSC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(update_kernel, dim3(grid_for(n / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    DSC_LAUNCH(update_kernel, dim3(grid_for(n / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const half_t*>(x), static_cast<const half_t*>(denoised),
                        static_cast<const half_t*>(old), a, b, c, static_cast<half_t*>(out), (long long)(n / 8));
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;

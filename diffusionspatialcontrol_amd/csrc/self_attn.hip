@@ -363,7 +363,7 @@ int launch(const SaParams& p0, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((self_attn_fwd<NK, WAVES, QT>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
+    DSC_LAUNCH((self_attn_fwd<NK, WAVES, QT>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 

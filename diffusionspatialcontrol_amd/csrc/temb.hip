@@ -75,7 +75,7 @@ extern "C" int dsc_linear_rows_f16(const void* x, const void* w, const void* bia
     hipStream_t st = static_cast<hipStream_t>(stream);
     const half_t* wp = static_cast<const half_t*>(w); const half_t* bp = static_cast<const half_t*>(bias);
     half_t* op = static_cast<half_t*>(out);
-#define DSC_ROWS(M_) hipLaunchKernelGGL(linear_rows_kernel<M_>, grid, block, 0, st, x, wp, bp, op, N, K, (long long)ldx, (long long)ldo, flags)
+#define DSC_ROWS(M_) DSC_LAUNCH(linear_rows_kernel<M_>, grid, block, 0, st, x, wp, bp, op, N, K, (long long)ldx, (long long)ldo, flags)
     switch (M) {
         case 1: DSC_ROWS(1); break;
         case 2: DSC_ROWS(2); break;
