@@ -101,3 +101,44 @@ class CompVisDenoiser(DiscreteEpsDDPMDenoiser):
 
     def get_eps(self, *args, **kwargs):
         return self.inner_model.apply_model(*args, **kwargs)
+
+
+class DiscreteVDDPMDenoiser(DiscreteSchedule):
+    """wraps a model that predicts v on a discrete DDPM schedule (reference external_k_diffusion.py:142-172)"""
+
+    def __init__(self, model, alphas_cumprod, quantize):
+        super().__init__(((1 - alphas_cumprod) / alphas_cumprod) ** 0.5, quantize)
+        self.inner_model = model
+        self.sigma_data = 1.0
+
+    def get_scalings(self, sigma):
+        sd2 = self.sigma_data ** 2
+        c_skip = sd2 / (sigma ** 2 + sd2)
+        c_out = -sigma * self.sigma_data / (sigma ** 2 + sd2) ** 0.5
+        c_in = 1 / (sigma ** 2 + sd2) ** 0.5
+        return c_skip, c_out, c_in
+
+    def get_v(self, *args, **kwargs):
+        return self.inner_model(*args, **kwargs)
+
+    def forward(self, input, sigma, **kwargs):
+        c_skip, c_out, c_in = (append_dims(s, input.ndim) for s in self.get_scalings(sigma))
+        vout = self.get_v(input * c_in, self.sigma_to_t(sigma), **kwargs) * c_out
+        return vout + input[:, :vout.shape[1]] * c_skip      # channel slice as in the eps wrapper (:169-171)
+
+
+class CompVisVDenoiser(DiscreteVDDPMDenoiser):
+    """the denoiser `setup_unet` builds for `prediction_type == "v_prediction"` (model_k_diffusion.py:138-139)"""
+
+    def __init__(self, model, quantize=False, device="cpu"):
+        super().__init__(model, model.alphas_cumprod, quantize=quantize)
+
+    # Reference defect kept on purpose (SURVEY.md Appendix E policy: decide and document): `get_v` forwards (x, t, cond)
+    # only (:181-182), so `cross_attention_kwargs` - and with it the region prompt - never reaches the UNet of a
+    # v-prediction model: the reference's spatial control is inert there.  pass_kwargs = True forwards them.
+    pass_kwargs = False
+
+    def get_v(self, x, t, cond, **kwargs):
+        if self.pass_kwargs:
+            return self.inner_model.apply_model(x, t, cond, **kwargs)
+        return self.inner_model.apply_model(x, t, cond)

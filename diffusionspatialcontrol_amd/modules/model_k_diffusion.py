@@ -31,7 +31,7 @@ import torch
 from .. import ops
 from . import sampling
 from .encode_region_map_function import encode_region_map
-from .external_k_diffusion import CompVisDenoiser
+from .external_k_diffusion import CompVisDenoiser, CompVisVDenoiser
 
 
 class ModelWrapper:
@@ -97,9 +97,9 @@ class StableDiffusionPipeline:
 
     def setup_unet(self, unet):
         self.unet = unet
-        if getattr(self.scheduler.config, "prediction_type", "epsilon") == "v_prediction":
-            raise NotImplementedError("v-prediction models are outside the SD1.5 hot path")
-        self.k_diffusion_model = CompVisDenoiser(ModelWrapper(unet, self.scheduler.alphas_cumprod))
+        model = ModelWrapper(unet, self.scheduler.alphas_cumprod)
+        self.v_prediction = getattr(self.scheduler.config, "prediction_type", "epsilon") == "v_prediction"      # :138-141
+        self.k_diffusion_model = CompVisVDenoiser(model) if self.v_prediction else CompVisDenoiser(model)
         self.k_diffusion_model.to(unet.device)
         self._graphs = {}
         self._drop_text_kv()
@@ -293,7 +293,7 @@ class StableDiffusionPipeline:
             added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
         self._added_cond_kwargs = added_cond_kwargs
         if fused is None:
-            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg
+            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg and not self.v_prediction
         if fused:
             latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout)
@@ -452,7 +452,8 @@ class StableDiffusionPipeline:
                                                           self.do_classifier_free_guidance)
             self._added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
         if fused is None:
-            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and self.do_classifier_free_guidance
+            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and self.do_classifier_free_guidance \
+                and not self.v_prediction
         if fused:
             latents = self._denoise_fused(latents, sigma_sched, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout)
@@ -717,6 +718,9 @@ class StableDiffusionPipeline:
 
     def _denoise_fused(self, latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                        cross_attention_kwargs, start_time, timeout):
+        if self.v_prediction:
+            raise NotImplementedError("the fused step (dsc_cfg_dpmpp2m_step) computes denoised = x - sigma * eps; "
+                                      "v-prediction models run in protocol mode (fused=False)")
         prof = os.environ.get("DSC_PROFILE_HOST") == "1"
         if prof:
             torch.cuda.synchronize()

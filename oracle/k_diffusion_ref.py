@@ -62,6 +62,19 @@ class DiscreteEpsDenoiser:
         return x[:, :eps.shape[1], ...] + eps * c_out
 
 
+class DiscreteVDenoiser(DiscreteEpsDenoiser):
+    """external_k_diffusion.py:142-172: the model output is v; pinned by tests/golden/vdenoiser.npz"""
+
+    def get_scalings(self, sigma):                                           # :150-154
+        sd2 = self.sigma_data ** 2
+        return sd2 / (sigma ** 2 + sd2), -sigma * self.sigma_data / (sigma ** 2 + sd2) ** 0.5, 1 / (sigma ** 2 + sd2) ** 0.5
+
+    def forward(self, v_fn, x, sigma, **kw):                                 # :166-171
+        c_skip, c_out, c_in = [s[(...,) + (None,) * (x.ndim - s.ndim)] for s in self.get_scalings(sigma)]
+        v = v_fn(x * c_in, self.sigma_to_t(sigma), **kw) * c_out
+        return v + x[:, :v.shape[1], ...] * c_skip
+
+
 def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
     """[parity unpinned] k_diffusion.sampling.get_sigmas_karras: n sigmas + trailing 0, fp32."""
     ramp = torch.linspace(0, 1, n)

@@ -125,12 +125,14 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
 
 
 def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None,
-                 sampler=None, sampler_kwargs=None, input_hook=None):
+                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False):
     """txt2img's loop for n_img images in the row layout [u_0.., c_0..]; returns the final latents (fp32).
 
     latents: initial noise ALREADY multiplied by sqrt(sigma_0^2 + 1) (model_k_diffusion.py:1043);
     sigmas: the schedule incl. trailing 0 (python floats or a tensor), text: [2*n_img, S, ctx]."""
-    den = kd.DiscreteEpsDenoiser(kd.sd15_alphas_cumprod())
+    # v-prediction: the reference's CompVisVDenoiser.get_v drops cross_attention_kwargs (external_k_diffusion.py:181-182),
+    # so its UNet never sees the region prompt
+    den = (kd.DiscreteVDenoiser if v_prediction else kd.DiscreteEpsDenoiser)(kd.sd15_alphas_cumprod())
     n_img = latents.shape[0]
     sig = [float(s) for s in sigmas]
     if steps_limit is not None:
@@ -146,7 +148,7 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
         rp = {"region_state": region_state, "sigma": float(sigma[0]), "weight_func": ra.default_weight_func}
 
         def eps_fn(xin, t, **kw):
-            return unet_forward(sd, cfg, xin, t, text, region_prompt=rp, n_std_groups=n_img)
+            return unet_forward(sd, cfg, xin, t, text, region_prompt=None if v_prediction else rp, n_std_groups=n_img)
 
         out = den.forward(eps_fn, inp, torch.cat([sigma] * 2))
         return kd.cfg_combine(out, guidance_scale)                                    # :1162-1166

@@ -48,8 +48,55 @@ def register_standins():
     sys.modules["k_diffusion"], sys.modules["k_diffusion.sampling"] = kd, ks
 
 
+def capture_vdenoiser():
+    """`DiscreteVDDPMDenoiser` / `CompVisVDenoiser` of the reference's external_k_diffusion.py (:142-182) on the SD1.5 schedule
+    -> tests/golden/vdenoiser.npz (scalings on a sigma grid, one forward with a recording inner model)"""
+    def append_dims(x, n):
+        return x[(...,) + (None,) * (n - x.ndim)]
+    sys.modules["k_diffusion"].utils = types.ModuleType("k_diffusion.utils")
+    sys.modules["k_diffusion"].utils.append_dims = append_dims
+    sys.modules["k_diffusion.utils"] = sys.modules["k_diffusion"].utils
+    sys.modules["k_diffusion.sampling"].append_zero = lambda x: torch.cat([x, x.new_zeros([1])])
+    spec = importlib.util.spec_from_file_location("ref_ekd", os.path.join(os.path.dirname(REF), "external_k_diffusion.py"))
+    ek = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ek)
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, dim=0)
+    calls = []
+
+    class Inner:
+        alphas_cumprod = acp
+
+        def apply_model(self, x, t, cond=None, **kw):
+            calls.append((x.clone(), t.clone(), sorted(kw)))
+            return torch.cos(x * 0.9) * 0.4 - 0.02 * t.reshape(-1, 1, 1, 1) / 1000.0
+
+    den = ek.CompVisVDenoiser(Inner())
+    out = {}
+    grid = torch.tensor([14.6146, 7.0944, 3.1686, 1.0, 0.2480, 0.029168], dtype=torch.float32)
+    out["grid"] = grid.numpy()
+    for name, v in zip(("c_skip", "c_out", "c_in"), den.get_scalings(grid)):
+        out[name] = v.numpy()
+    out["sigmas"] = den.sigmas.numpy()
+    rng = np.random.default_rng(78)
+    x = torch.from_numpy(rng.standard_normal((2, 6, 8, 8)).astype(np.float32))      # 6 channels in, 4 out: the channel slice
+    sig = torch.tensor([2.5])
+
+    class Inner4(Inner):
+        def apply_model(self, x, t, cond=None, **kw):
+            return Inner.apply_model(self, x, t, cond, **kw)[:, :4]
+    den4 = ek.CompVisVDenoiser(Inner4())
+    out["fwd_x"], out["fwd_sigma"] = x.numpy(), sig.numpy()
+    out["fwd_out"] = den4(x, sig, cond=None, cross_attention_kwargs={"k": 1}).numpy()
+    out["fwd_inner_x"], out["fwd_inner_t"] = calls[-1][0].numpy(), calls[-1][1].numpy()
+    out["kwargs_reach_the_model"] = np.int64(len(calls[-1][2]))                       # 0: the reference drops them (:181-182)
+    np.savez_compressed(os.path.join(HERE, "vdenoiser.npz"), **out)
+    print("vdenoiser.npz", {k: np.shape(v) for k, v in out.items()})
+
+
 def main():
     register_standins()
+    capture_vdenoiser()
     spec = importlib.util.spec_from_file_location("ref_samplers_extra", REF)
     ref = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref)

@@ -412,3 +412,36 @@ def test_vae_structure_and_image_side_helpers():
     assert im.shape == (1, 3, 4, 4) and float(im.max()) == -1.0
     with pytest.raises(NotImplementedError):
         pipe._encode_vae_image(torch.zeros(1, 3, 8, 8), None)
+
+
+def test_v_prediction_denoiser_matches_reference_golden():
+    """DiscreteVDDPMDenoiser / CompVisVDenoiser (reference external_k_diffusion.py:142-182) against outputs of the reference's
+    own classes (tests/golden/vdenoiser.npz), and the pipeline's `setup_unet` choice (:138-141)"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "vdenoiser.npz"))
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1.0 - betas, dim=0)
+    seen = []
+
+    class Inner:
+        alphas_cumprod = acp
+
+        def apply_model(self, x, t, cond=None, **kw):
+            seen.append((x.clone(), t.clone(), sorted(kw)))
+            return (torch.cos(x * 0.9) * 0.4 - 0.02 * t.reshape(-1, 1, 1, 1) / 1000.0)[:, :4]
+
+    den = ek.CompVisVDenoiser(Inner())
+    assert np.allclose(den.sigmas.numpy(), g["sigmas"], rtol=1e-6)
+    for name, v in zip(("c_skip", "c_out", "c_in"), den.get_scalings(torch.from_numpy(g["grid"]))):
+        assert np.allclose(v.numpy(), g[name], rtol=1e-6, atol=1e-7), name
+    out = den(torch.from_numpy(g["fwd_x"]), torch.from_numpy(g["fwd_sigma"]), cond=None, cross_attention_kwargs={"k": 1})
+    assert np.abs(out.numpy() - g["fwd_out"]).max() < 1e-5
+    assert np.abs(seen[-1][0].numpy() - g["fwd_inner_x"]).max() < 1e-6 and np.abs(seen[-1][1].numpy() - g["fwd_inner_t"]).max() < 1e-3
+    assert len(seen[-1][2]) == int(g["kwargs_reach_the_model"]) == 0          # the reference drops the kwargs: kept (documented)
+    den.pass_kwargs = True
+    den(torch.from_numpy(g["fwd_x"]), torch.from_numpy(g["fwd_sigma"]), cond=None, cross_attention_kwargs={"k": 1})
+    assert seen[-1][2] == ["cross_attention_kwargs"]
+    unet = UNet2DConditionModel(UNetConfig.tiny()).half()
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler(prediction_type="v_prediction"))
+    assert isinstance(pipe.k_diffusion_model, ek.CompVisVDenoiser) and pipe.v_prediction
+    with pytest.raises(NotImplementedError):
+        pipe._denoise_fused(None, None, None, None, None, 7.5, 1, {}, -1, 0)

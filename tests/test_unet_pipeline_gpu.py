@@ -531,6 +531,28 @@ def test_other_samplers_protocol_vs_oracle(ops, name, opt):
     assert (out - ref).abs().mean().item() < 6e-3 * scale
 
 
+def test_v_prediction_pipeline_vs_oracle(ops):
+    """prediction_type == "v_prediction": CompVisVDenoiser in protocol mode against the oracle's v-denoiser loop (the
+    reference drops the region prompt on this branch - reproduced; `pass_kwargs` restores it)"""
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    cfg, unet, sd, text = _tiny_setup(1)
+    state, ids, rs = _region_state(n_img=1)
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler(prediction_type="v_prediction"))
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(5)).half()
+    kw = dict(height=128, width=128, num_inference_steps=5, guidance_scale=7.5, latents=lat.clone(), output_type="latent",
+              region_map_state=state, sampler_name="sample_dpmpp_2m", sampler_opt={"scheduler": "karras"},
+              prompt_embeds=text[1:2], negative_prompt_embeds=text[:1], text_input_ids=ids)
+    out = pipe.txt2img(None, **kw)[0].float().cpu()
+    sig = pipe.get_sigmas(5, {"scheduler": "karras"}).half().float().cpu()
+    ref = unet_ref.denoise_loop(sd, cfg, lat.float() * math.sqrt(float(sig[0]) ** 2 + 1), sig.tolist(), text.float(), rs, 7.5,
+                                v_prediction=True)
+    scale = ref.abs().max().item()
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() < 4e-2 * scale
+    pipe.k_diffusion_model.pass_kwargs = True
+    ctl = pipe.txt2img(None, **kw)[0].float().cpu()
+    assert (ctl - out).abs().max().item() > 1e-3 * scale               # with the kwargs forwarded the region bias is live
+
+
 def test_sd15_unet_step_full_size(ops):
     """Full-size SD1.5 UNet (random weights, seed 0), one CFG step with the region bias at all 16 cross-attention
     layers: finite output, the bias is live, and a repeat is BIT-IDENTICAL - every convolution of the step now runs on
