@@ -305,6 +305,9 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
     // residual pixels of this thread's four output chunks: issued before the staging pass so that their latency hides
     // under it (the skip tensor was written by an earlier kernel: Infinity Cache / HBM)
     h8_t rpre[4];
+    h8_t bpre = {0, 0, 0, 0, 0, 0, 0, 0};                           // bias of this thread's chunk column (the same in all four passes)
+    if (p.bias && p.splits == 1 && !p.nchw && n0 + (int)(threadIdx.x & 7) * 8 + 8 <= p.Cout)
+        bpre = *reinterpret_cast<const h8_t*>(p.bias + n0 + (threadIdx.x & 7) * 8);
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
         rpre[cidx] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
@@ -352,9 +355,7 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
             const int c0 = n0 + ch * 8;
             if (c0 >= p.Cout) continue;                              // channel padding of a ragged last tile
             if (c0 + 8 <= p.Cout && !p.nchw) {
-                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0};
-                const h8_t rv = rpre[cidx];
-                if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + c0);
+                const h8_t bv = bpre, rv = rpre[cidx];
                 h8_t o;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)rv[jj]);

@@ -123,6 +123,25 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
     // folded LayerNorm: thread t < 128 owns row m0 + t's (mean, 1/std); the partial-sum loads ride under the K loop
     float ln_mu = 0.f, ln_rs = 1.f;
     if (p.ln_in && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) row_stats(p, m0 + threadIdx.x, ln_mu, ln_rs);
+    // column constants of this thread's epilogue chunks (its chunk column is the same in every pass): bias and, for a folded
+    // LayerNorm, the weight-row sums - fetched here so that their latency rides under the K loop, not in the epilogue
+    const int ech = GEGLU ? (threadIdx.x & 3) : (threadIdx.x & 7);
+    h8_t bpre0 = {0, 0, 0, 0, 0, 0, 0, 0}, bpre1 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f4x_t cpre[GEGLU ? 4 : 2];
+#pragma unroll
+    for (int i = 0; i < (GEGLU ? 4 : 2); ++i) cpre[i] = f4x_t{0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        bpre0 = *reinterpret_cast<const h8_t*>(p.bias + n0 + ech * 8);
+        if (GEGLU) bpre1 = *reinterpret_cast<const h8_t*>(p.bias + Nh + n0 + ech * 8);
+    }
+    if (p.ln_in) {
+        cpre[0] = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ech * 8);
+        cpre[1] = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ech * 8 + 4);
+        if (GEGLU) {
+            cpre[2] = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ech * 8);
+            cpre[3] = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ech * 8 + 4);
+        }
+    }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % STAGES;
         // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (6 DMA instructions each) are outstanding
@@ -179,16 +198,11 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
             if (m0 + row < p.M) {
                 const float* sp = stage + row * kEpiStride + ch * 8;
-                const h8_t bh = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
-                const h8_t bg = *reinterpret_cast<const h8_t*>(p.bias + Nh + n0 + ch * 8);
+                const h8_t bh = bpre0, bg = bpre1;                 // ch == ech: T is a multiple of the chunks per row
                 h8_t o;
-                float ch_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cg_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (p.ln_in) {
-                    const f4x_t a0 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8), a1 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8 + 4);
-                    const f4x_t g0 = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ch * 8), g1 = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ch * 8 + 4);
+                float ch_[8], cg_[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { ch_[j] = a0[j]; ch_[4 + j] = a1[j]; cg_[j] = g0[j]; cg_[4 + j] = g1[j]; }
-                }
+                for (int j = 0; j < 4; ++j) { ch_[j] = cpre[0][j]; ch_[4 + j] = cpre[1][j]; cg_[j] = cpre[GEGLU ? 2 : 0][j]; cg_[4 + j] = cpre[GEGLU ? 3 : 1][j]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float ah = sp[j], ag = sp[32 + j];
@@ -214,16 +228,11 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
             if (live) {
                 const float* sp = stage + row * kEpiStride + ch * 8;
-                h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0};
-                const h8_t rv = rpre[c];
-                if (p.bias) bv = *reinterpret_cast<const h8_t*>(p.bias + n0 + ch * 8);
+                const h8_t bv = bpre0, rv = rpre[c];               // ch == ech
                 h8_t o;
-                float cv_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (p.ln_in) {
-                    const f4x_t a0 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8), a1 = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ch * 8 + 4);
+                float cv_[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { cv_[j] = a0[j]; cv_[4 + j] = a1[j]; }
-                }
+                for (int j = 0; j < 4; ++j) { cv_[j] = cpre[0][j]; cv_[4 + j] = cpre[1][j]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float a = sp[j];
