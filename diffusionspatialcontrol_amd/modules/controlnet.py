@@ -1,0 +1,148 @@
+"""ControlNet - the network that produces the `down_block_additional_residuals` / `mid_block_additional_residual` the UNet
+wrapper accepts (reference `u_net_condition_modify.py:1194-1245,1269-1270`) and that the reference pipeline calls in its
+`model_fn` (`model_k_diffusion.py:348-427` setup / preprocessing, `:1118-1152` per-step call).
+
+diffusers 0.27.2 `ControlNetModel` / `MultiControlNetModel` are un-vendored; restated from the published structure
+(Zhang et al. 2023; diffusers parameter names, so `load_state_dict` of a ControlNet checkpoint works): the UNet's encoder half
+(conv_in, time embedding, four down blocks, mid block - the SAME modules as modules/u_net_condition_modify.py, hence the same
+HIP kernels), a conditioning embedding (eight 3x3 convolutions, 3 -> 16 -> 32 -> 96 -> 256 -> 320 channels, three of them
+stride 2, SiLU between them) added to conv_in's output, and one zero-initialised 1x1 convolution per skip tensor / mid output.
+**Parity unpinned** (diffusers absent); structural check: 361,279,120 parameters in the SD1.5 configuration (the published
+ControlNet v1.1 size); oracle restatement on shared weights: oracle/unet_ref.py `controlnet_forward`.
+
+The conditioning embedding depends only on the control image: it is computed once per image tensor and reused by every step.
+"""
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .u_net_condition_modify import (Conv1x1, TimestepEmbedding, UNetConfig, UNetMidBlock, _Block, _Config, _EncoderHalf,
+                                     _image, _tokens)
+
+
+class ControlNetConditioningEmbedding(nn.Module):
+    def __init__(self, conditioning_embedding_channels, conditioning_channels=3, block_out_channels=(16, 32, 96, 256)):
+        super().__init__()
+        ch = block_out_channels
+        self.conv_in = nn.Conv2d(conditioning_channels, ch[0], 3, padding=1)
+        self.blocks = nn.ModuleList()
+        for i in range(len(ch) - 1):
+            self.blocks.append(nn.Conv2d(ch[i], ch[i], 3, padding=1))
+            self.blocks.append(nn.Conv2d(ch[i], ch[i + 1], 3, padding=1, stride=2))
+        self.conv_out = nn.Conv2d(ch[-1], conditioning_embedding_channels, 3, padding=1)
+        nn.init.zeros_(self.conv_out.weight)
+        nn.init.zeros_(self.conv_out.bias)
+
+    def forward(self, conditioning):
+        h = F.silu(self.conv_in(conditioning))
+        for blk in self.blocks:
+            h = F.silu(blk(h))
+        return self.conv_out(h)
+
+
+class ControlNetModel(_EncoderHalf, nn.Module):
+    def __init__(self, cfg: Optional[UNetConfig] = None, conditioning_channels=3,
+                 conditioning_embedding_out_channels=(16, 32, 96, 256), global_pool_conditions=False):
+        super().__init__()
+        cfg = cfg or UNetConfig.sd15()
+        self.cfg = cfg
+        self.config = _Config(in_channels=cfg.in_channels, cross_attention_dim=cfg.cross_attention_dim,
+                              block_out_channels=cfg.block_out_channels, global_pool_conditions=global_pool_conditions)
+        ch = cfg.block_out_channels
+        n = len(ch)
+        td = cfg.time_embed_dim
+        self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], td)
+        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(ch[0], conditioning_channels,
+                                                                         conditioning_embedding_out_channels)
+        self.down_blocks = nn.ModuleList()
+        self.controlnet_down_blocks = nn.ModuleList([self._zero_conv(ch[0])])
+        cin = ch[0]
+        for i, c in enumerate(ch):
+            io = [(cin if j == 0 else c, c) for j in range(cfg.layers_per_block)]
+            self.down_blocks.append(_Block(io, td, cfg, cfg.num_attention_heads[i], cfg.transformer_layers_per_block[i],
+                                           down=i < n - 1))
+            for _ in range(cfg.layers_per_block + (1 if i < n - 1 else 0)):
+                self.controlnet_down_blocks.append(self._zero_conv(c))
+            cin = c
+        self.mid_block = UNetMidBlock(ch[-1], td, cfg, cfg.num_attention_heads[-1], cfg.mid_transformer_layers)
+        self.controlnet_mid_block = self._zero_conv(ch[-1])
+        self._channels_last = False
+        self._cond_cache = None
+
+    @staticmethod
+    def _zero_conv(c):
+        conv = Conv1x1(c, c)
+        nn.init.zeros_(conv.weight)
+        nn.init.zeros_(conv.bias)
+        return conv
+
+    def _resnets(self):
+        out = []
+        for blk in self.down_blocks:
+            out += list(blk.resnets)
+        return out + list(self.mid_block.resnets)
+
+    def _cond_embedding(self, controlnet_cond):
+        """channels-last [B, 320, h, w]; cached per control-image tensor (identity + in-place version): it does not depend on
+        the step"""
+        key = (id(controlnet_cond), controlnet_cond._version, tuple(controlnet_cond.shape), controlnet_cond.dtype)
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            emb = self.controlnet_cond_embedding(controlnet_cond.to(self.dtype).contiguous())
+            self._cond_cache = (key, emb.contiguous(memory_format=torch.channels_last), controlnet_cond)
+        return self._cond_cache[1]
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale: float = 1.0,
+                class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
+                cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = True):
+        if attention_mask is not None:
+            raise NotImplementedError("attention masks are not on the hot path (never passed by app.py)")
+        temb_act = self._time_act(sample, timestep)
+        self._to_channels_last_once()
+        x = self._conv_in(sample) + self._cond_embedding(controlnet_cond)
+        tadd = self._all_temb_adds(temb_act)
+        skips, x = self._run_down(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
+        x = self._run_mid(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
+        down = [zc(s) for s, zc in zip(skips, self.controlnet_down_blocks)]
+        mid = self.controlnet_mid_block(x)
+        if guess_mode and not self.config.global_pool_conditions:
+            scales = torch.logspace(-1, 0, len(down) + 1, device=sample.device) * conditioning_scale   # 0.1 .. 1.0
+            down = [d * sc for d, sc in zip(down, scales)]
+            mid = mid * scales[-1]
+        else:
+            down = [d * conditioning_scale for d in down]
+            mid = mid * conditioning_scale
+        if self.config.global_pool_conditions:
+            down = [d.mean(dim=(2, 3), keepdim=True) for d in down]
+            mid = mid.mean(dim=(2, 3), keepdim=True)
+        if not return_dict:
+            return down, mid
+        return type("ControlNetOutput", (), {"down_block_res_samples": down, "mid_block_res_sample": mid})()
+
+
+class MultiControlNetModel(nn.Module):
+    """diffusers `MultiControlNetModel`: several ControlNets, residuals summed (reference `setup_controlnet` :348-353)"""
+
+    def __init__(self, controlnets: Union[List[ControlNetModel], Tuple[ControlNetModel]]):
+        super().__init__()
+        self.nets = nn.ModuleList(controlnets)
+
+    @property
+    def dtype(self):
+        return self.nets[0].dtype
+
+    def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, class_labels=None,
+                timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
+                guess_mode: bool = False, return_dict: bool = True):
+        down_sum, mid_sum = None, None
+        for image, scale, net in zip(controlnet_cond, conditioning_scale, self.nets):
+            down, mid = net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
+                            cross_attention_kwargs=cross_attention_kwargs)
+            if down_sum is None:
+                down_sum, mid_sum = down, mid
+            else:
+                down_sum = [a + b for a, b in zip(down_sum, down)]
+                mid_sum = mid_sum + mid
+        return down_sum, mid_sum

@@ -108,6 +108,92 @@ class StableDiffusionPipeline:
         """reference :143-146 resolves the name in `k_diffusion.sampling`; here in the build's own sampling module"""
         return getattr(importlib.import_module(sampling.__name__), scheduler_type)
 
+    def setup_controlnet(self, controlnet):
+        """reference :348-353"""
+        from .controlnet import MultiControlNetModel
+        if isinstance(controlnet, (list, tuple)):
+            controlnet = MultiControlNetModel(controlnet)
+        self.controlnet = controlnet
+
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype,
+                      do_classifier_free_guidance=False, guess_mode=False):
+        """reference :483-515: the control image in [0, 1] (no normalisation) at (height, width), duplicated for CFG"""
+        if not isinstance(image, torch.Tensor):
+            image = (self._image_tensor(image, height, width) + 1.0) / 2.0
+        elif tuple(image.shape[-2:]) != (height, width):
+            image = torch.nn.functional.interpolate(image.float(), size=(height, width), mode="bilinear")
+        image = image.to(device=device, dtype=dtype)
+        if do_classifier_free_guidance and not guess_mode:
+            image = torch.cat([image] * 2)
+        return image
+
+    def preprocess_controlnet(self, controlnet_conditioning_scale, control_guidance_start, control_guidance_end, image, width,
+                              height, num_inference_steps, batch_size, num_images_per_prompt):
+        """reference :355-427: (control image(s), keep schedule, guess_mode, conditioning scale(s))"""
+        from .controlnet import ControlNetModel, MultiControlNetModel
+        controlnet = self.controlnet
+        multi = isinstance(controlnet, MultiControlNetModel)
+        if not isinstance(control_guidance_start, list) and isinstance(control_guidance_end, list):
+            control_guidance_start = len(control_guidance_end) * [control_guidance_start]
+        elif not isinstance(control_guidance_end, list) and isinstance(control_guidance_start, list):
+            control_guidance_end = len(control_guidance_start) * [control_guidance_end]
+        elif not isinstance(control_guidance_start, list) and not isinstance(control_guidance_end, list):
+            mult = len(controlnet.nets) if multi else 1
+            control_guidance_start, control_guidance_end = mult * [control_guidance_start], mult * [control_guidance_end]
+        if multi and isinstance(controlnet_conditioning_scale, float):
+            controlnet_conditioning_scale = [controlnet_conditioning_scale] * len(controlnet.nets)
+        first = controlnet.nets[0] if multi else controlnet
+        guess_mode = bool(first.config.global_pool_conditions)
+        prep = lambda im: self.prepare_image(im, width, height, batch_size, num_images_per_prompt, self._execution_device,  # noqa: E731
+                                             controlnet.dtype, self.do_classifier_free_guidance, guess_mode)
+        if multi:
+            image = [prep(im) for im in image]
+        elif isinstance(controlnet, ControlNetModel):
+            image = prep(image)
+        else:
+            raise TypeError("setup_controlnet() takes a ControlNetModel or a list of them")
+        keep = []
+        for i in range(num_inference_steps):
+            keeps = [1.0 - float(i / num_inference_steps < s or (i + 1) / num_inference_steps > e)
+                     for s, e in zip(control_guidance_start, control_guidance_end)]
+            keep.append(keeps if multi else keeps[0])
+        return image, keep, guess_mode, controlnet_conditioning_scale
+
+    def _controlnet_hook(self, control_img, controlnet_conditioning_scale, control_guidance_start, control_guidance_end,
+                         width, height, n_steps, n_img, num_images_per_prompt, text):
+        """The per-call ControlNet evaluation of the reference's model_fn (:1118-1152) as a function
+        (latent_model_input, sigma) -> UNet keyword arguments; None when no ControlNet is set up."""
+        if self.controlnet is None:
+            return None
+        if control_img is None:
+            raise ValueError("a ControlNet is set up (setup_controlnet): pass control_img")
+        scale = 1.0 if controlnet_conditioning_scale is None else controlnet_conditioning_scale
+        start = 0.0 if control_guidance_start is None else control_guidance_start
+        end = 1.0 if control_guidance_end is None else control_guidance_end
+        img, keep, guess_mode, scale = self.preprocess_controlnet(scale, start, end, control_img, width, height, n_steps,
+                                                                  n_img, num_images_per_prompt)
+        seen = []
+        kdm = self.k_diffusion_model
+        cfg = self.do_classifier_free_guidance
+
+        def hook(latent_model_input, sigma):
+            key = float(sigma[0])                               # one control step per DISTINCT sigma, in call order (:1119-1123)
+            if key not in seen:
+                seen.append(key)
+            k = keep[min(len(seen) - 1, len(keep) - 1)]
+            if isinstance(k, list):
+                cond_scale = [c * s_ for c, s_ in zip(scale, k)]
+            else:
+                cond_scale = (scale[0] if isinstance(scale, list) else scale) * k
+            down, mid = self.controlnet(latent_model_input / ((sigma[0] ** 2 + 1) ** 0.5), kdm.sigma_to_t(sigma),
+                                        encoder_hidden_states=text, controlnet_cond=img, conditioning_scale=cond_scale,
+                                        guess_mode=guess_mode, return_dict=False)
+            if guess_mode and cfg:                              # inferred for the conditional rows only (:1143-1148)
+                down = [torch.cat([torch.zeros_like(d), d]) for d in down]
+                mid = torch.cat([torch.zeros_like(mid), mid])
+            return {"down_block_additional_residuals": down, "mid_block_additional_residual": mid}
+        return hook
+
     def get_sigmas(self, steps, params):
         """reference :848-882"""
         discard = params.get("discard_next_to_last_sigma", False)
@@ -248,15 +334,15 @@ class StableDiffusionPipeline:
                 output_type: Optional[str] = "pil", callback_steps: Optional[int] = 1, upscale=False,
                 region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
                 latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), seed=0,
-                ip_adapter_image=None, control_img=None, image_t2i_adapter=None, guidance_rescale: float = 0.0,
+                ip_adapter_image=None, control_img=None, controlnet_conditioning_scale=None, control_guidance_start=None,
+                control_guidance_end=None, image_t2i_adapter=None, guidance_rescale: float = 0.0,
                 cross_attention_kwargs=None, clip_skip=None, long_encode=0, num_images_per_prompt=1,
                 ip_adapter_image_embeds=None,
                 # build-specific inputs (the prompt encoders are a "next" row):
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                 text_input_ids=None, fused: Optional[bool] = None, **unsupported):
-        if upscale or ip_adapter_image is not None or control_img is not None \
-                or image_t2i_adapter is not None or self.controlnet is not None or latent_processing:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images (CLIP image encoder) / ControlNet / "
+        if upscale or ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing:
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images (CLIP image encoder) / "
                                       "T2I-Adapter / latent previews are outside the denoising hot path built here "
                                       "(SURVEY.md 8f); pass ip_adapter_image_embeds for IP-Adapter")
         sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
@@ -292,15 +378,22 @@ class StableDiffusionPipeline:
             embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt, cfg)
             added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
         self._added_cond_kwargs = added_cond_kwargs
+        control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
+                                             control_guidance_end, width, height, num_inference_steps, n_img,
+                                             num_images_per_prompt, text)                                    # :1060-1061
         if fused is None:
-            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg and not self.v_prediction
+            fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg and not self.v_prediction \
+                and control_hook is None
         if fused:
+            if control_hook is not None:
+                raise NotImplementedError("ControlNet runs in protocol mode (fused=False): the captured step graph holds the UNet only")
             latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout)
         else:
             latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                              guidance_rescale, n_img, cross_attention_kwargs, eta,
-                                             num_inference_steps, sampler_opt, seed, start_time, timeout)
+                                             num_inference_steps, sampler_opt, seed, start_time, timeout,
+                                             control_hook=control_hook)
         return [self.latent_to_image(latents, output_type)]
 
     def get_sampler_extra_args_i2i(self, sigmas, steps, sampler_opt, latents, seed, func):
@@ -407,7 +500,9 @@ class StableDiffusionPipeline:
                 generator: Optional[torch.Generator] = None, image=None, output_type: Optional[str] = "pil", latents=None,
                 strength=1.0, region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
                 scale_ratio=8.0, latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), upscale=False,
-                width=None, height=None, seed=0, ip_adapter_image=None, control_img=None, image_t2i_adapter=None,
+                width=None, height=None, seed=0, ip_adapter_image=None, control_img=None,
+                controlnet_conditioning_scale=None, control_guidance_start=None, control_guidance_end=None,
+                image_t2i_adapter=None,
                 guidance_rescale: float = 0.0, cross_attention_kwargs=None, clip_skip=None, long_encode=0,
                 num_images_per_prompt=1, ip_adapter_image_embeds=None,
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
@@ -415,9 +510,8 @@ class StableDiffusionPipeline:
         """reference :543-846: encode the image (or take `latents`), keep the last `strength` fraction of the schedule, add
         noise, denoise.  Reproduces the reference's start: `latents + noise * sqrt(sigma_0^2 + 1)` (:647 - sic, not
         `noise * sigma_0`)."""
-        if upscale or ip_adapter_image is not None or control_img is not None or image_t2i_adapter is not None \
-                or self.controlnet is not None or latent_processing:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images / ControlNet / T2I-Adapter / latent "
+        if upscale or ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing:
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images / T2I-Adapter / latent "
                                       "previews are outside the denoising hot path built here (SURVEY.md 8f)")
         sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
         device = self._execution_device
@@ -451,17 +545,23 @@ class StableDiffusionPipeline:
             embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt,
                                                           self.do_classifier_free_guidance)
             self._added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
+        control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
+                                             control_guidance_end, width, height, len(sigma_sched), n_img,
+                                             num_images_per_prompt, text)                                    # :675-676
         if fused is None:
             fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and self.do_classifier_free_guidance \
-                and not self.v_prediction
+                and not self.v_prediction and control_hook is None
         if fused:
+            if control_hook is not None:
+                raise NotImplementedError("ControlNet runs in protocol mode (fused=False)")
             latents = self._denoise_fused(latents, sigma_sched, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout)
         else:
             args = self.get_sampler_extra_args_i2i(sigma_sched, len(sigma_sched), sampler_opt, latents, seed, sampler)
             latents = self._denoise_protocol(sampler, latents, sigma_sched, text, region_state, weight_func, guidance_scale,
                                              guidance_rescale, n_img, cross_attention_kwargs, 0.0, len(sigma_sched),
-                                             sampler_opt, seed, start_time, timeout, sampler_args=args)
+                                             sampler_opt, seed, start_time, timeout, sampler_args=args,
+                                             control_hook=control_hook)
         return [self.latent_to_image(latents, output_type)]
 
     def _sigma_to_alpha_sigma_t(self, sigma):
@@ -507,7 +607,8 @@ class StableDiffusionPipeline:
                   output_type: Optional[str] = "pil", callback_steps: Optional[int] = 1, upscale=False,
                   region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
                   latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), seed=0,
-                  ip_adapter_image=None, control_img=None, image_t2i_adapter=None, image=None, mask_image=None,
+                  ip_adapter_image=None, control_img=None, controlnet_conditioning_scale=None, control_guidance_start=None,
+                  control_guidance_end=None, image_t2i_adapter=None, image=None, mask_image=None,
                   masked_image_latents=None, padding_mask_crop=None, strength: float = 1.0, guidance_rescale: float = 0.0,
                   cross_attention_kwargs=None, clip_skip=None, long_encode=0, num_images_per_prompt=1,
                   ip_adapter_image_embeds=None,
@@ -516,9 +617,9 @@ class StableDiffusionPipeline:
         """reference :1365-1760 (method name as spelled there), the 4-channel UNet branch: the known region
         `image_latents + sigma * noise` is re-imposed on the model input before every model call after the first
         (:1599-1612).  Protocol mode only (the blend is a hook on the model input)."""
-        if upscale or ip_adapter_image is not None or control_img is not None or image_t2i_adapter is not None \
-                or self.controlnet is not None or latent_processing or padding_mask_crop is not None:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images / ControlNet / T2I-Adapter / latent "
+        if upscale or ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing \
+                or padding_mask_crop is not None:
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images / T2I-Adapter / latent "
                                       "previews / mask cropping are outside the denoising hot path built here")
         if self.unet.config.in_channels != 4:
             raise NotImplementedError("the 9-channel inpainting UNet (mask + masked-image latents concatenated to the "
@@ -567,15 +668,19 @@ class StableDiffusionPipeline:
             rate = (s ** 2 + 1) ** 0.5
             return ((1 - mask) * known + mask * x / rate) * rate
 
+        control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
+                                             control_guidance_end, width, height, num_inference_steps, n_img,
+                                             num_images_per_prompt, text)                                    # :1577-1578
         latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                          guidance_rescale, n_img, cross_attention_kwargs, eta, num_inference_steps,
-                                         sampler_opt, seed, start_time, timeout, input_hook=keep_known_region)
+                                         sampler_opt, seed, start_time, timeout, input_hook=keep_known_region,
+                                         control_hook=control_hook)
         return [self.latent_to_image(latents, output_type)]
 
     # ---- protocol mode: the reference's model_fn closure (:1091-1171) + sampler call (:1172-1175)
     def _denoise_protocol(self, sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                           guidance_rescale, n_img, cross_attention_kwargs, eta, steps, sampler_opt, seed, start_time,
-                          timeout, sampler_args=None, input_hook=None):
+                          timeout, sampler_args=None, input_hook=None, control_hook=None):
         """sampler_args: the keyword arguments for `sampler` when the caller built them itself (img2img's
         get_sampler_extra_args_i2i); input_hook(x, sigma, call_index) -> x: applied to the model input (inpainting's
         re-imposition of the known region, reference :1599-1612)"""
@@ -598,6 +703,8 @@ class StableDiffusionPipeline:
             # only works for B == 1 in the reference; repeat sigma per row so that B > 1 works too
             sig_rows = torch.cat([sigma] * 2) if cfg else sigma
             extra_kw = {} if self._added_cond_kwargs is None else {"added_cond_kwargs": self._added_cond_kwargs}
+            if control_hook is not None:
+                extra_kw.update(control_hook(latent_model_input, sig_rows))
             noise_pred = kdm(latent_model_input, sig_rows, cond=text, cross_attention_kwargs=cross_attention_kwargs,
                              **extra_kw)
             if cfg:

@@ -501,7 +501,116 @@ class _Config(dict):
     __getattr__ = dict.get
 
 
-class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
+class _EncoderHalf:
+    """The part of the forward pass UNet2DConditionModel and ControlNetModel (modules/controlnet.py) share: time embedding,
+    conv_in, down blocks, mid block.  Needs `cfg`, `conv_in`, `time_embedding`, `down_blocks`, `mid_block`, `_resnets()`."""
+
+    def time_proj(self, timesteps, dim):
+        """sinusoidal Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) (reference :554); fractional t allowed."""
+        half = dim // 2
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half)
+        ang = timesteps.float()[:, None] * freqs[None]
+        return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+    def _time_act(self, sample, timestep):
+        """SiLU(time_embedding(Timesteps(t))) [B, time_embed_dim] - every ResnetBlock applies SiLU to temb first"""
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], dtype=torch.float32, device=sample.device)
+        timestep = timestep.reshape(-1).expand(sample.shape[0])
+        te = self.time_embedding
+        if sample.is_cuda and sample.dtype == torch.float16 and sample.shape[0] <= 8:
+            # Timesteps -> linear_1 -> SiLU -> linear_2 -> SiLU as two few-row GEMV launches (13 kernels before)
+            h1 = ops.linear_rows(timestep.float(), te.linear_1.weight, te.linear_1.bias, silu_out=True,
+                                 sinusoid_dim=self.cfg.block_out_channels[0])
+            return ops.linear_rows(h1, te.linear_2.weight, te.linear_2.bias, silu_out=True)
+        emb = te(self.time_proj(timestep, self.cfg.block_out_channels[0]).to(sample.dtype))
+        return F.silu(emb)
+
+    def _few_channel_convs(self):
+        return [c for c in (self.conv_in, getattr(self, "conv_out", None)) if c is not None]
+
+    def _to_channels_last_once(self):
+        if not self._channels_last:                              # conv weights to NHWC once: no per-call transposes
+            self.to(memory_format=torch.channels_last)
+            # MIOpen has no NHWC implicit-GEMM for 4 channels (it falls back to a 300-400 us naive kernel):
+            # the 4-channel convolutions run NCHW and convert at the boundary when the hand-written kernels do not apply
+            for conv in self._few_channel_convs():
+                conv.weight.data = conv.weight.data.contiguous()
+            self._channels_last = True
+
+    def _conv_in(self, sample):
+        ci = self.conv_in
+        if (sample.is_cuda and sample.dtype == torch.float16 and ci.in_channels <= 8 and ci.out_channels % 8 == 0
+                and ci.out_channels <= 512 and sample.shape[-1] % 8 == 0 and ops.USE_DSC_CONV):
+            wt = _derived(self, "conv_in_t", (ci.weight,), lambda: ci.weight.reshape(ci.out_channels, -1).t().contiguous())
+            return ops.conv3x3_fewcin(sample, wt, ci.bias, ci.out_channels)   # NCHW latents -> NHWC features, one launch
+        return ci(sample.contiguous()).contiguous(memory_format=torch.channels_last)
+
+    def _run_down(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs):
+        skips = [x]
+        for blk in self.down_blocks:
+            for j, res in enumerate(blk.resnets):
+                x = res(x, temb_act, tadd[res])
+                if blk.has_attn:
+                    x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
+                skips.append(x)
+            if hasattr(blk, "downsamplers"):
+                x = blk.downsamplers[0](x)
+                skips.append(x)
+        return skips, x
+
+    def _run_mid(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs):
+        x = self.mid_block.resnets[0](x, temb_act, tadd[self.mid_block.resnets[0]])
+        for attn in self.mid_block.attentions:
+            x = attn(x, encoder_hidden_states, cross_attention_kwargs)
+        return self.mid_block.resnets[1](x, temb_act, tadd[self.mid_block.resnets[1]])
+
+    def _all_temb_adds(self, temb_act):
+        """the per-ResNet `time_emb_proj(silu(temb))` GEMMs ([B,1280] x [cout,1280]; 22 in the SD1.5 UNet) as ONE GEMM over
+        the concatenated weights; returns {resnet: [B, cout] view}.  Offsets are multiples of 8 (16-byte aligned rows)."""
+        res = self._resnets()
+        deps = tuple(p for r in res for p in (r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias))
+        W, Bv = _derived(self, "temb", deps, lambda: (torch.cat([r.time_emb_proj.weight for r in res]).contiguous(),
+                                                       torch.cat([r.time_emb_proj.bias + r.conv1.bias for r in res])))
+        if temb_act.is_cuda and temb_act.dtype == torch.float16 and temb_act.shape[0] <= 8:
+            allp = ops.linear_rows(temb_act, W, Bv)
+        else:
+            allp = F.linear(temb_act, W, Bv)
+        out, off = {}, 0
+        for r in res:
+            n = r.time_emb_proj.out_features
+            out[r] = allp[:, off:off + n]
+            off += n
+        return out
+
+    # ---- processor plumbing (reference :689-749)
+    @property
+    def attn_processors(self):
+        return {f"{name}.processor": m.get_processor() for name, m in self.named_modules() if isinstance(m, Attention)}
+
+    def set_attn_processor(self, processor):
+        attns = [(name, m) for name, m in self.named_modules() if isinstance(m, Attention)]
+        if isinstance(processor, dict):
+            if len(processor) != len(attns):
+                raise ValueError(
+                    f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
+                    f" number of attention layers: {len(attns)}. Please make sure to pass {len(attns)} processor classes.")
+            for name, m in attns:
+                m.set_processor(processor.pop(f"{name}.processor"))
+        else:
+            for _, m in attns:
+                m.set_processor(processor)
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+
+class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_modify):
     def __init__(self, cfg: Optional[UNetConfig] = None):
         super().__init__()
         cfg = cfg or UNetConfig.sd15()
@@ -548,112 +657,26 @@ class UNet2DConditionModel(nn.Module, UNet2DConditionLoadersMixin_modify):
             out += list(blk.resnets)
         return out
 
-    def _all_temb_adds(self, temb_act):
-        """the 22 per-ResNet `time_emb_proj(silu(temb))` GEMMs ([B,1280] x [cout,1280]) as ONE GEMM over the
-        concatenated weights; returns {resnet: [B, cout] view}.  Offsets are multiples of 8 (16-byte aligned rows)."""
-        res = self._resnets()
-        deps = tuple(p for r in res for p in (r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias))
-        W, Bv = _derived(self, "temb", deps, lambda: (torch.cat([r.time_emb_proj.weight for r in res]).contiguous(),
-                                                       torch.cat([r.time_emb_proj.bias + r.conv1.bias for r in res])))
-        if temb_act.is_cuda and temb_act.dtype == torch.float16 and temb_act.shape[0] <= 8:
-            allp = ops.linear_rows(temb_act, W, Bv)
-        else:
-            allp = F.linear(temb_act, W, Bv)
-        out, off = {}, 0
-        for r in res:
-            n = r.time_emb_proj.out_features
-            out[r] = allp[:, off:off + n]
-            off += n
-        return out
-
-    # ---- processor plumbing (reference :689-749)
-    @property
-    def attn_processors(self):
-        return {f"{name}.processor": m.get_processor() for name, m in self.named_modules() if isinstance(m, Attention)}
-
-    def set_attn_processor(self, processor):
-        attns = [(name, m) for name, m in self.named_modules() if isinstance(m, Attention)]
-        if isinstance(processor, dict):
-            if len(processor) != len(attns):
-                raise ValueError(
-                    f"A dict of processors was passed, but the number of processors {len(processor)} does not match the"
-                    f" number of attention layers: {len(attns)}. Please make sure to pass {len(attns)} processor classes.")
-            for name, m in attns:
-                m.set_processor(processor.pop(f"{name}.processor"))
-        else:
-            for _, m in attns:
-                m.set_processor(processor)
-
-    @property
-    def dtype(self):
-        return self.conv_in.weight.dtype
-
-    @property
-    def device(self):
-        return self.conv_in.weight.device
-
-    def time_proj(self, timesteps, dim):
-        """sinusoidal Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) (reference :554); fractional t allowed."""
-        half = dim // 2
-        freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half)
-        ang = timesteps.float()[:, None] * freqs[None]
-        return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
-
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
         if attention_mask is not None or encoder_attention_mask is not None:
             raise NotImplementedError("attention masks are not on the hot path (never passed by app.py)")
-        if not torch.is_tensor(timestep):
-            timestep = torch.tensor([timestep], dtype=torch.float32, device=sample.device)
-        timestep = timestep.reshape(-1).expand(sample.shape[0])
-        te = self.time_embedding
-        if sample.is_cuda and sample.dtype == torch.float16 and sample.shape[0] <= 8:
-            # Timesteps -> linear_1 -> SiLU -> linear_2 -> SiLU as two few-row GEMV launches (13 kernels before)
-            h1 = ops.linear_rows(timestep.float(), te.linear_1.weight, te.linear_1.bias, silu_out=True,
-                                 sinusoid_dim=self.cfg.block_out_channels[0])
-            temb_act = ops.linear_rows(h1, te.linear_2.weight, te.linear_2.bias, silu_out=True)
-        else:
-            emb = te(self.time_proj(timestep, self.cfg.block_out_channels[0]).to(sample.dtype))
-            temb_act = F.silu(emb)                               # every ResnetBlock applies SiLU to temb first
-        if not self._channels_last:                              # conv weights to NHWC once: no per-call transposes
-            self.to(memory_format=torch.channels_last)
-            # MIOpen has no NHWC implicit-GEMM for 4 channels (it falls back to a 300-400 us naive kernel):
-            # the two 4-channel convolutions run NCHW and convert at the boundary (a 2.6 MB copy each)
-            for conv in (self.conv_in, self.conv_out):
-                conv.weight.data = conv.weight.data.contiguous()
-            self._channels_last = True
+        temb_act = self._time_act(sample, timestep)
+        self._to_channels_last_once()
         if getattr(self, "encoder_hid_proj", None) is not None and self.config.get("encoder_hid_dim_type") == "ip_image_proj":
             # reference :1030-1037 - the IP-Adapter image tokens travel with the text as a tuple
             if added_cond_kwargs is None or "image_embeds" not in added_cond_kwargs:
                 raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
                                  "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
             encoder_hidden_states = (encoder_hidden_states, self.encoder_hid_proj(added_cond_kwargs.get("image_embeds")))
-        ci = self.conv_in
-        if (sample.is_cuda and sample.dtype == torch.float16 and ci.in_channels <= 8 and ci.out_channels % 8 == 0
-                and ci.out_channels <= 512 and sample.shape[-1] % 8 == 0 and ops.USE_DSC_CONV):
-            wt = _derived(self, "conv_in_t", (ci.weight,), lambda: ci.weight.reshape(ci.out_channels, -1).t().contiguous())
-            x = ops.conv3x3_fewcin(sample, wt, ci.bias, ci.out_channels)     # NCHW latents -> NHWC features, one launch
-        else:
-            x = ci(sample.contiguous()).contiguous(memory_format=torch.channels_last)
+        x = self._conv_in(sample)
         tadd = self._all_temb_adds(temb_act)
-        skips = [x]
-        for blk in self.down_blocks:
-            for j, res in enumerate(blk.resnets):
-                x = res(x, temb_act, tadd[res])
-                if blk.has_attn:
-                    x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
-                skips.append(x)
-            if hasattr(blk, "downsamplers"):
-                x = blk.downsamplers[0](x)
-                skips.append(x)
+        skips, x = self._run_down(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
         if down_block_additional_residuals is not None:          # ControlNet hook (reference :1236-1245)
             skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
-        x = self.mid_block.resnets[0](x, temb_act, tadd[self.mid_block.resnets[0]])
-        for attn in self.mid_block.attentions:
-            x = attn(x, encoder_hidden_states, cross_attention_kwargs)
-        x = self.mid_block.resnets[1](x, temb_act, tadd[self.mid_block.resnets[1]])
+        x = self._run_mid(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
         if mid_block_additional_residual is not None:            # reference :1269-1270
             x = x + mid_block_additional_residual
         for blk in self.up_blocks:

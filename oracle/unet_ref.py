@@ -84,9 +84,8 @@ def _transformer(sd, pre, x, enc, heads, groups, region_prompt, n_std_groups):
     return x + res
 
 
-def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_groups=1):
-    """cfg: any object with block_out_channels, num_attention_heads, norm_num_groups, norm_eps."""
-    sd = {k: v.float() for k, v in sd.items()}
+def _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups, add_to_conv_in=None):
+    """time embedding, conv_in (+ an optional additive term: ControlNet's conditioning embedding), down blocks, mid block"""
     ch, heads_l, G, eps = cfg.block_out_channels, cfg.num_attention_heads, cfg.norm_num_groups, cfg.norm_eps
     half = ch[0] // 2
     freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
@@ -94,7 +93,8 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
     temb = torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)               # flip_sin_to_cos=True, freq_shift=0
     temb = _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", temb)))
     x = _conv(sd, "conv_in", sample.float())
-    enc = enc.float()
+    if add_to_conv_in is not None:
+        x = x + add_to_conv_in
     skips = [x]
     for i in range(len(ch)):
         j = 0
@@ -111,6 +111,42 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
     if "mid_block.attentions.0.norm.weight" in sd:
         x = _transformer(sd, "mid_block.attentions.0", x, enc, heads_l[-1], G, region_prompt, n_std_groups)
     x = _resnet(sd, "mid_block.resnets.1", x, temb, G, eps)
+    return temb, skips, x
+
+
+def controlnet_forward(sd, cfg, sample, timestep, enc, controlnet_cond, conditioning_scale=1.0, guess_mode=False):
+    """diffusers 0.27.2 `ControlNetModel.forward` (un-vendored; the call the reference's model_fn makes,
+    model_k_diffusion.py:1134-1142): conditioning embedding (SiLU between its convolutions) added to conv_in's output, the
+    UNet encoder half WITHOUT a region prompt (the reference passes no cross_attention_kwargs to the ControlNet), one 1x1
+    convolution per skip tensor and for the mid output, times conditioning_scale (guess mode: times logspace(-1, 0)).
+    Returns (down residuals, mid residual).  Parity unpinned."""
+    sd = {k: v.float() for k, v in sd.items()}
+    h = F.silu(_conv(sd, "controlnet_cond_embedding.conv_in", controlnet_cond.float()))
+    i = 0
+    while f"controlnet_cond_embedding.blocks.{i}.weight" in sd:
+        h = F.silu(_conv(sd, f"controlnet_cond_embedding.blocks.{i}", h, stride=2 if i % 2 else 1))
+        i += 1
+    h = _conv(sd, "controlnet_cond_embedding.conv_out", h)
+    _, skips, x = _encoder_half(sd, cfg, sample, timestep, enc.float(), None, 1, add_to_conv_in=h)
+    down = [_conv(sd, f"controlnet_down_blocks.{k}", s_, padding=0) for k, s_ in enumerate(skips)]
+    mid = _conv(sd, "controlnet_mid_block", x, padding=0)
+    if guess_mode:
+        scales = torch.logspace(-1, 0, len(down) + 1) * conditioning_scale
+        return [d * sc for d, sc in zip(down, scales)], mid * scales[-1]
+    return [d * conditioning_scale for d in down], mid * conditioning_scale
+
+
+def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_groups=1, down_residuals=None, mid_residual=None):
+    """cfg: any object with block_out_channels, num_attention_heads, norm_num_groups, norm_eps.  down_residuals /
+    mid_residual: the ControlNet hooks of reference u_net_condition_modify.py:1236-1245,1269-1270."""
+    sd = {k: v.float() for k, v in sd.items()}
+    ch, heads_l, G, eps = cfg.block_out_channels, cfg.num_attention_heads, cfg.norm_num_groups, cfg.norm_eps
+    enc = enc.float()
+    temb, skips, x = _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups)
+    if down_residuals is not None:
+        skips = [s_ + r for s_, r in zip(skips, down_residuals)]
+    if mid_residual is not None:
+        x = x + mid_residual
     rev_heads = list(reversed(heads_l))
     for i in range(len(ch)):
         j = 0
@@ -125,7 +161,7 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
 
 
 def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None,
-                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False):
+                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False, controlnet=None):
     """txt2img's loop for n_img images in the row layout [u_0.., c_0..]; returns the final latents (fp32).
 
     latents: initial noise ALREADY multiplied by sqrt(sigma_0^2 + 1) (model_k_diffusion.py:1043);
@@ -139,6 +175,7 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
         sig = sig[:steps_limit + 1]
 
     calls = [0]
+    seen_sigmas = []
 
     def model_fn(x, sigma):
         if input_hook is not None:                     # inpainting: the known region re-imposed on the model input (:1599-1612)
@@ -148,7 +185,18 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
         rp = {"region_state": region_state, "sigma": float(sigma[0]), "weight_func": ra.default_weight_func}
 
         def eps_fn(xin, t, **kw):
-            return unet_forward(sd, cfg, xin, t, text, region_prompt=None if v_prediction else rp, n_std_groups=n_img)
+            down, mid = None, None
+            if controlnet is not None:
+                # {"sd", "cond" [2 n_img rows], "scale": one value per DISTINCT sigma in call order}; the ControlNet sees the
+                # duplicated latent divided by sqrt(sigma^2 + 1) and the same t (model_k_diffusion.py:1118-1142)
+                s_key = float(sigma[0])
+                if s_key not in seen_sigmas:
+                    seen_sigmas.append(s_key)
+                scale = controlnet["scale"][len(seen_sigmas) - 1]
+                down, mid = controlnet_forward(controlnet["sd"], cfg, inp / ((sigma[0] ** 2 + 1) ** 0.5), t, text,
+                                               controlnet["cond"], scale, controlnet.get("guess_mode", False))
+            return unet_forward(sd, cfg, xin, t, text, region_prompt=None if v_prediction else rp, n_std_groups=n_img,
+                                down_residuals=down, mid_residual=mid)
 
         out = den.forward(eps_fn, inp, torch.cat([sigma] * 2))
         return kd.cfg_combine(out, guidance_scale)                                    # :1162-1166

@@ -445,3 +445,32 @@ def test_v_prediction_denoiser_matches_reference_golden():
     assert isinstance(pipe.k_diffusion_model, ek.CompVisVDenoiser) and pipe.v_prediction
     with pytest.raises(NotImplementedError):
         pipe._denoise_fused(None, None, None, None, None, 7.5, 1, {}, -1, 0)
+
+
+def test_controlnet_structure_and_schedule():
+    """ControlNetModel: the published SD1.5 ControlNet size, diffusers key names, zero-initialised output convolutions; the
+    pipeline's keep schedule / conditioning scales (reference model_k_diffusion.py:355-427)"""
+    from diffusionspatialcontrol_amd.modules.controlnet import ControlNetModel, MultiControlNetModel
+    with torch.device("meta"):
+        cn = ControlNetModel()
+    assert sum(p.numel() for p in cn.parameters()) == 361279120
+    keys = set(cn.state_dict().keys())
+    assert {"controlnet_cond_embedding.conv_in.weight", "controlnet_cond_embedding.blocks.5.bias",
+            "controlnet_cond_embedding.conv_out.weight", "controlnet_down_blocks.11.weight", "controlnet_mid_block.bias",
+            "down_blocks.2.attentions.1.transformer_blocks.0.attn2.to_k.weight", "mid_block.resnets.1.conv2.weight"} <= keys
+    assert not any(k.startswith("up_blocks") or k.startswith("conv_out") for k in keys)
+    tiny = ControlNetModel(UNetConfig.tiny())
+    assert len(tiny.controlnet_down_blocks) == 12 and float(tiny.controlnet_mid_block.weight.abs().max()) == 0.0
+    assert float(tiny.controlnet_cond_embedding.conv_out.weight.abs().max()) == 0.0
+    unet = UNet2DConditionModel(UNetConfig.tiny()).half()
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    pipe.setup_controlnet(tiny)
+    img = torch.rand(1, 3, 32, 32)
+    im, keep, guess, scale = pipe.preprocess_controlnet(0.8, 0.0, 0.5, img, 64, 64, 4, 1, 1)
+    assert im.shape == (2, 3, 64, 64) and keep == [1.0, 1.0, 0.0, 0.0] and not guess and scale == 0.8      # CFG duplicates the image
+    pipe.setup_controlnet([tiny, ControlNetModel(UNetConfig.tiny())])
+    assert isinstance(pipe.controlnet, MultiControlNetModel)
+    im, keep, guess, scale = pipe.preprocess_controlnet(0.5, [0.0, 0.5], 1.0, [img, img], 64, 64, 2, 1, 1)
+    assert len(im) == 2 and keep == [[1.0, 0.0], [1.0, 1.0]] and scale == [0.5, 0.5]
+    with pytest.raises(ValueError):
+        pipe._controlnet_hook(None, None, None, None, 64, 64, 2, 1, 1, None)

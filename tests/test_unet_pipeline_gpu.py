@@ -867,6 +867,81 @@ def test_img2img_and_inpainting_pipeline(ops):
         pipe.inpaiting(None, image=lat0, mask_image=mask, padding_mask_crop=8, **common)
 
 
+def _controlnet(cfg, seed=5):
+    """a ControlNet with its zero-initialised convolutions re-drawn (otherwise every residual is zero)"""
+    from diffusionspatialcontrol_amd.modules.controlnet import ControlNetModel
+    torch.manual_seed(seed)
+    cn = ControlNetModel(cfg)
+    for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+        torch.nn.init.normal_(conv.weight, 0.0, 0.15)
+        torch.nn.init.normal_(conv.bias, 0.0, 0.05)
+    cn = cn.half()
+    return cn, {k: v.clone() for k, v in cn.state_dict().items()}
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_controlnet_forward_matches_oracle(ops, full):
+    """ControlNetModel (the UNet's encoder half + conditioning embedding + 1x1 output convolutions) against the fp32 oracle on
+    shared weights: toy width, and the SD1.5 geometry at a 32x32 latent."""
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNetConfig
+    cfg = UNetConfig.sd15() if full else UNetConfig.tiny()
+    cn, sd = _controlnet(cfg)
+    cn = cn.cuda().eval()
+    g = torch.Generator().manual_seed(8)
+    hw = 32 if full else 16
+    x = torch.randn(2, 4, hw, hw, generator=g).half()
+    enc = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).half()
+    cond = torch.rand(2, 3, hw * 8, hw * 8, generator=g).half()
+    t = torch.tensor([321.5, 321.5])
+    with torch.no_grad():
+        down, mid = cn(x.cuda(), t.cuda(), enc.cuda(), cond.cuda(), conditioning_scale=0.7, return_dict=False)
+        rdown, rmid = unet_ref.controlnet_forward(sd, cfg, x.float(), t, enc.float(), cond.float(), 0.7)
+    assert len(down) == 12
+    for a, b in zip(down + [mid], rdown + [rmid]):
+        sc = max(b.abs().max().item(), 1e-3)
+        assert a.shape == b.shape and (a.float().cpu() - b).abs().max().item() < 2e-2 * sc, (a.shape, sc)
+    with torch.no_grad():      # guess mode: residual k scaled by logspace(-1, 0, 13)[k]
+        d2, m2 = cn(x.cuda(), t.cuda(), enc.cuda(), cond.cuda(), conditioning_scale=1.0, guess_mode=True, return_dict=False)
+        rd2, rm2 = unet_ref.controlnet_forward(sd, cfg, x.float(), t, enc.float(), cond.float(), 1.0, guess_mode=True)
+    for a, b in zip(d2 + [m2], rd2 + [rm2]):
+        assert (a.float().cpu() - b).abs().max().item() < 2e-2 * max(b.abs().max().item(), 1e-3)
+
+
+def test_controlnet_pipeline_vs_oracle(ops):
+    """txt2img with a ControlNet (reference model_k_diffusion.py:1118-1152): every model call evaluates the ControlNet on the
+    duplicated latent / sqrt(sigma^2 + 1) and hands its residuals to the UNet; guidance window [0, 0.6] switches it off for the
+    last steps.  Product (protocol mode) against the oracle loop with the oracle ControlNet."""
+    from diffusionspatialcontrol_amd.modules import sampling
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    cfg, unet, sd, text = _tiny_setup(1)
+    state, ids, rs = _region_state(n_img=1)
+    cn, cn_sd = _controlnet(cfg)
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    pipe.setup_controlnet(cn.cuda().eval())
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(6)).half()
+    ctrl = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(7))
+    steps = 5
+    kw = dict(height=128, width=128, num_inference_steps=steps, guidance_scale=7.5, latents=lat.clone(), output_type="latent",
+              region_map_state=state, sampler_name="sample_dpmpp_2m", sampler_opt={"scheduler": "karras"},
+              prompt_embeds=text[1:2], negative_prompt_embeds=text[:1], text_input_ids=ids)
+    out = pipe.txt2img(None, control_img=ctrl, controlnet_conditioning_scale=0.9, control_guidance_start=0.0,
+                       control_guidance_end=0.6, **kw)[0].float().cpu()
+    sig = pipe.get_sigmas(steps, {"scheduler": "karras"}).half().float().cpu()
+    keep = [1.0 - float(i / steps < 0.0 or (i + 1) / steps > 0.6) for i in range(steps)]
+    assert keep == [1.0, 1.0, 1.0, 0.0, 0.0]
+    control = {"sd": cn_sd, "cond": torch.cat([ctrl.half().float()] * 2), "scale": [0.9 * k for k in keep]}
+    ref = unet_ref.denoise_loop(sd, cfg, lat.float() * math.sqrt(float(sig[0]) ** 2 + 1), sig.tolist(), text.float(), rs, 7.5,
+                                controlnet=control)
+    scale = ref.abs().max().item()
+    assert torch.isfinite(out).all() and (out - ref).abs().max().item() < 4e-2 * scale, ((out - ref).abs().max().item(), scale)
+    pipe.setup_controlnet(None)
+    plain = pipe.txt2img(None, fused=False, **kw)[0].float().cpu()
+    assert (plain - out).abs().max().item() > 1e-2 * scale                # the ControlNet residuals are live
+    pipe.setup_controlnet(cn)
+    with pytest.raises(NotImplementedError):
+        pipe.txt2img(None, control_img=ctrl, fused=True, **kw)
+
+
 def test_ip_adapter_unet_and_pipeline(ops):
     """IP-Adapter weights load into the UNet with the published key numbering (cross-attention
     layers numbered 1, 3, 5, ... over down_blocks, up_blocks, mid_block), the image tokens reach every cross-attention
