@@ -460,8 +460,8 @@ def test_controlnet_structure_and_schedule():
             "down_blocks.2.attentions.1.transformer_blocks.0.attn2.to_k.weight", "mid_block.resnets.1.conv2.weight"} <= keys
     assert not any(k.startswith("up_blocks") or k.startswith("conv_out") for k in keys)
     tiny = ControlNetModel(UNetConfig.tiny())
-    assert len(tiny.controlnet_down_blocks) == 12 and float(tiny.controlnet_mid_block.weight.abs().max()) == 0.0
-    assert float(tiny.controlnet_cond_embedding.conv_out.weight.abs().max()) == 0.0
+    assert len(tiny.controlnet_down_blocks) == 12 and float(tiny.controlnet_mid_block.weight.detach().abs().max()) == 0.0
+    assert float(tiny.controlnet_cond_embedding.conv_out.weight.detach().abs().max()) == 0.0
     unet = UNet2DConditionModel(UNetConfig.tiny()).half()
     pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
     pipe.setup_controlnet(tiny)
