@@ -70,6 +70,12 @@ class EulerDiscreteScheduler:
             self._step_index = int((self.timesteps == timestep).nonzero()[0].item())
         return self._step_index
 
+    def add_noise(self, original_samples, noise, timesteps):
+        """diffusers EulerDiscreteScheduler.add_noise: x0 + sigma(t) * noise (sigma looked up by timestep VALUE)"""
+        t = timesteps.reshape(-1)[0] if torch.is_tensor(timesteps) else timesteps
+        idx = int((self.timesteps.to(torch.float32).cpu() == float(t)).nonzero()[0].item())
+        return original_samples + float(self.sigmas[idx]) * noise
+
     def scale_model_input(self, sample, timestep):
         sigma = float(self.sigmas[self._index(timestep)])
         return sample / ((sigma ** 2 + 1) ** 0.5)
@@ -135,6 +141,22 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
         latents = self.prepare_latents(n_img, self.unet.config.in_channels, height, width, text.dtype, device, generator,
                                        latents)
         latents = latents * float(self.scheduler.init_noise_sigma)                                    # diffusers prepare_latents
+        fixed = None
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            fixed = {"down_block_additional_residuals": down_block_additional_residuals,
+                     "mid_block_additional_residual": mid_block_additional_residual}
+        latents = self._denoise(latents, ts, text, region_state, weight_func, guidance_scale, guidance_rescale,
+                                added_cond_kwargs, ca_kwargs, callback_on_step_end, fixed_residuals=fixed)
+        return [self.latent_to_image(latents, output_type)]
+
+    def _denoise(self, latents, ts, text, region_state, weight_func, guidance_scale, guidance_rescale, added_cond_kwargs,
+                 ca_kwargs, callback_on_step_end=None, fixed_residuals=None, control=None, after_step=None):
+        """The loop every pipeline of reference model_diffusers.py runs (t2i :340-407; the others repeat it): per scheduler
+        timestep - CFG duplication, scale_model_input, region_prompt with `sigma = scheduler.sigmas[i]` (i = LOOP index: the
+        img2img / inpaint variants thereby read the UN-truncated schedule, SURVEY.md quirk q5 - kept), optional ControlNet call
+        on the scaled input, ONE UNet call, `u + g (c - u)`, optional rescale, scheduler.step, optional post-step hook
+        (inpainting's re-imposition of the known region)."""
+        cfg = self.do_classifier_free_guidance
         self._text_kv_for(text)
         for i, t in enumerate(ts):
             x_in = torch.cat([latents] * 2) if cfg else latents                                       # :345
@@ -142,22 +164,240 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
             ca_kwargs["region_prompt"] = {"region_state": region_state, "sigma": self.scheduler.sigmas[i],
                                           "weight_func": weight_func}                                 # :349-354 (whole-batch std)
             ukw = {} if added_cond_kwargs is None else {"added_cond_kwargs": added_cond_kwargs}
+            if fixed_residuals is not None:
+                ukw.update(fixed_residuals)
+            if control is not None:                                                                   # :700-760 of the ControlNet classes
+                keep = control["keep"][i]
+                if isinstance(keep, list):
+                    cond_scale = [c_ * s_ for c_, s_ in zip(control["scale"], keep)]
+                else:
+                    sc_ = control["scale"]
+                    cond_scale = (sc_[0] if isinstance(sc_, list) else sc_) * keep
+                down, mid = self.controlnet(x_in.to(text.dtype), t, encoder_hidden_states=text, controlnet_cond=control["image"],
+                                            conditioning_scale=cond_scale, guess_mode=control["guess_mode"], return_dict=False)
+                ukw.update({"down_block_additional_residuals": down, "mid_block_additional_residual": mid})
             eps = self.unet(x_in.to(text.dtype), t, encoder_hidden_states=text, cross_attention_kwargs=ca_kwargs,
-                            down_block_additional_residuals=down_block_additional_residuals,
-                            mid_block_additional_residual=mid_block_additional_residual, return_dict=False, **ukw)[0]
+                            return_dict=False, **ukw)[0]
             if cfg:
                 u, c = eps.chunk(2)
                 eps = u + guidance_scale * (c - u)                                                    # :381-383
                 if guidance_rescale > 0.0:
                     eps = rescale_noise_cfg(eps, c, guidance_rescale=guidance_rescale)                # :385-387
             latents = self.scheduler.step(eps, t, latents, return_dict=False)[0]                      # :390
+            if after_step is not None:
+                latents = after_step(i, t, latents)
             if callback_on_step_end is not None:
                 out = callback_on_step_end(self, i, t, {"latents": latents})
                 latents = out.pop("latents", latents)
         self._drop_text_kv()
-        return [self.latent_to_image(latents, output_type)]
+        return latents
 
     def _text_kv_for(self, text):
         """project (and pack) the text K/V of every cross-attention layer once for the whole loop (the text does not
         change between steps); the k-diffusion pipeline's helper works on its static buffers, here on the plain tensor"""
         self._refresh_text_kv(text)
+
+
+    # ---- pieces shared by the other five classes
+    def _prepare_call(self, prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, text_input_ids, guidance_scale,
+                      num_images_per_prompt, clip_skip, long_encode, ip_adapter_image_embeds, region_map_state, width, height,
+                      cross_attention_kwargs):
+        device = self._execution_device
+        self._do_classifier_free_guidance = guidance_scale > 1.0
+        text, text_input_ids, n_img = self._encode_text_rows(prompt, negative_prompt, prompt_embeds, negative_prompt_embeds,
+                                                             text_input_ids, num_images_per_prompt, clip_skip or None,
+                                                             long_encode, device)
+        added = None
+        if ip_adapter_image_embeds is not None:
+            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, n_img,
+                                                          self.do_classifier_free_guidance)
+            added = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
+        region_state = encode_region_map(self, region_map_state, width=width, height=height,
+                                         num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)
+        return device, text, n_img, added, region_state, ({} if cross_attention_kwargs is None else dict(cross_attention_kwargs))
+
+    def get_timesteps(self, num_inference_steps, strength, device):
+        """diffusers img2img `get_timesteps`: keep the last int(n * strength) steps"""
+        init_timestep = min(int(num_inference_steps * strength), num_inference_steps)
+        t_start = max(num_inference_steps - init_timestep, 0)
+        return self.scheduler.timesteps[t_start * self.scheduler.order:], num_inference_steps - t_start
+
+    def _image_latents(self, image, n_img, dtype, device, generator):
+        """4-channel tensors are latents already; pixels go through the VAE encoder (posterior sample x scaling factor)"""
+        if isinstance(image, torch.Tensor) and image.shape[1] == 4:
+            lat = image.to(device=device, dtype=dtype)
+        else:
+            lat = self._encode_vae_image(self.preprocess(image), generator).to(device=device, dtype=dtype)
+        return lat.repeat(n_img // lat.shape[0], 1, 1, 1)
+
+    def _control(self, control_image, controlnet_conditioning_scale, control_guidance_start, control_guidance_end, width,
+                 height, n_steps, n_img, num_images_per_prompt):
+        if self.controlnet is None:
+            raise ValueError("this pipeline needs a ControlNet: construct it with controlnet=... or call setup_controlnet()")
+        image, keep, guess_mode, scale = self.preprocess_controlnet(controlnet_conditioning_scale, control_guidance_start,
+                                                                    control_guidance_end, control_image, width, height,
+                                                                    n_steps, n_img, num_images_per_prompt)
+        return {"image": image, "keep": keep, "guess_mode": guess_mode, "scale": scale}
+
+
+class StableDiffusionImg2ImgPipeline_finetune(StableDiffusionPipeline_finetune):
+    """reference model_diffusers.py:1228-1513: encode the image, `scheduler.add_noise` at the first kept timestep, run the
+    last `strength` fraction of the schedule."""
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, strength: float = 0.8, num_inference_steps: int = 50, timesteps=None,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0,
+                 generator=None, prompt_embeds=None, negative_prompt_embeds=None, ip_adapter_image=None,
+                 ip_adapter_image_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 cross_attention_kwargs=None, guidance_rescale: float = 0.0, clip_skip=0, region_map_state=None,
+                 weight_func=lambda w, sigma, qk: w * sigma * qk.std(), latent_processing=0, callback_on_step_end=None,
+                 image_t2i_adapter=None, long_encode=0, text_input_ids=None, height=None, width=None,
+                 control_image=None, controlnet_conditioning_scale=1.0, control_guidance_start=0.0, control_guidance_end=1.0,
+                 **kwargs):
+        if ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing or timesteps is not None:
+            raise NotImplementedError("raw IP-Adapter images, T2I-Adapter, latent previews and custom timestep lists are "
+                                      "'next' rows (SURVEY.md 8f)")
+        if image is None:
+            raise ValueError("img2img needs `image` (pixels in [-1, 1] / PIL, or 4-channel latents)")
+        if strength < 0 or strength > 1:
+            raise ValueError(f"The value of strength should in [0.0, 1.0] but is {strength}")
+        if height is None or width is None:
+            hh, ww = (image.shape[-2:] if isinstance(image, torch.Tensor) else image.size[::-1])
+            f = 8 if (isinstance(image, torch.Tensor) and image.shape[1] == 4) else 1
+            height, width = height or int(hh) * f, width or int(ww) * f
+        device, text, n_img, added, region_state, ca = self._prepare_call(
+            prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, text_input_ids, guidance_scale,
+            num_images_per_prompt, clip_skip, long_encode, ip_adapter_image_embeds, region_map_state, width, height,
+            cross_attention_kwargs)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        ts, _ = self.get_timesteps(num_inference_steps, strength, device)
+        if len(ts) < 1:
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of "
+                             "pipeline steps is 0 which is < 1 and not appropriate for this pipeline.")
+        init = self._image_latents(image, n_img, text.dtype, device, generator)
+        noise = self._randn_like_ref(init.shape, generator, device, text.dtype)
+        latents = self.scheduler.add_noise(init, noise, ts[:1])
+        control = None
+        if control_image is not None or self._needs_control:
+            control = self._control(control_image, controlnet_conditioning_scale, control_guidance_start, control_guidance_end,
+                                    width, height, len(ts), n_img, num_images_per_prompt)
+        latents = self._denoise(latents, ts, text, region_state, weight_func, guidance_scale, guidance_rescale, added, ca,
+                                callback_on_step_end, control=control)
+        return [self.latent_to_image(latents, output_type)]
+
+    _needs_control = False
+
+
+StableDiffusionPipeline_finetune._needs_control = False
+
+
+class StableDiffusionInpaintPipeline_finetune(StableDiffusionPipeline_finetune):
+    """reference model_diffusers.py:1515-1918, the 4-channel UNet branch of diffusers' inpainting loop: after every scheduler
+    step the known region is re-imposed - `(1 - mask) * add_noise(image_latents, noise, t_next) + mask * latents`."""
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, mask_image=None, masked_image_latents=None, height=None, width=None,
+                 padding_mask_crop=None, strength: float = 1.0, num_inference_steps: int = 50, timesteps=None,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0,
+                 generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, ip_adapter_image=None,
+                 ip_adapter_image_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 cross_attention_kwargs=None, guidance_rescale: float = 0.0, clip_skip=0, region_map_state=None,
+                 weight_func=lambda w, sigma, qk: w * sigma * qk.std(), latent_processing=0, callback_on_step_end=None,
+                 image_t2i_adapter=None, long_encode=0, text_input_ids=None,
+                 control_image=None, controlnet_conditioning_scale=1.0, control_guidance_start=0.0, control_guidance_end=1.0,
+                 **kwargs):
+        if ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing or timesteps is not None \
+                or padding_mask_crop is not None:
+            raise NotImplementedError("raw IP-Adapter images, T2I-Adapter, latent previews, custom timestep lists and mask "
+                                      "cropping are 'next' rows (SURVEY.md 8f)")
+        if self.unet.config.in_channels != 4:
+            raise NotImplementedError("the 9-channel inpainting UNet is a 'next' row (conv_in kernel: <= 8 input channels)")
+        if image is None or mask_image is None:
+            raise ValueError("inpainting needs `image` and `mask_image`")
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        device, text, n_img, added, region_state, ca = self._prepare_call(
+            prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, text_input_ids, guidance_scale,
+            num_images_per_prompt, clip_skip, long_encode, ip_adapter_image_embeds, region_map_state, width, height,
+            cross_attention_kwargs)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        ts, _ = self.get_timesteps(num_inference_steps, strength, device)
+        if len(ts) < 1:
+            raise ValueError("After adjusting the num_inference_steps by strength parameter, the number of pipeline steps is 0")
+        is_strength_max = strength == 1.0
+        init_image = image if (isinstance(image, torch.Tensor) and image.shape[1] == 4) else self._image_tensor(image, height, width)
+        image_latents = self._image_latents(init_image, n_img, text.dtype, device, generator)
+        noise = self._randn_like_ref(image_latents.shape, generator, device, text.dtype) if latents is None \
+            else latents.to(device=device, dtype=text.dtype)
+        if is_strength_max or latents is not None:          # diffusers prepare_latents: passed latents are pure noise
+            x = noise * float(self.scheduler.init_noise_sigma)
+        else:
+            x = self.scheduler.add_noise(image_latents, noise, ts[:1])
+        mask = self._image_tensor(mask_image, height, width, mask=True)
+        mask = torch.nn.functional.interpolate(mask, size=(height // self.vae_scale_factor, width // self.vae_scale_factor))
+        mask = mask.to(device=device, dtype=text.dtype)
+        if mask.shape[0] < n_img:
+            mask = mask.repeat(n_img // mask.shape[0], 1, 1, 1)
+
+        def keep_known(i, t, lat):
+            known = image_latents
+            if i < len(ts) - 1:
+                known = self.scheduler.add_noise(known, noise, ts[i + 1:i + 2])
+            return (1 - mask) * known + mask * lat
+
+        control = None
+        if control_image is not None or self._needs_control:
+            control = self._control(control_image, controlnet_conditioning_scale, control_guidance_start, control_guidance_end,
+                                    width, height, len(ts), n_img, num_images_per_prompt)
+        x = self._denoise(x, ts, text, region_state, weight_func, guidance_scale, guidance_rescale, added, ca,
+                          callback_on_step_end, control=control, after_step=keep_known)
+        return [self.latent_to_image(x, output_type)]
+
+
+class _WithControlNet:
+    """constructor of the three ControlNet classes: diffusers puts `controlnet` between `unet` and `scheduler`"""
+    _needs_control = True
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, controlnet, scheduler, feature_extractor=None, image_encoder=None):
+        super().__init__(vae, text_encoder, tokenizer, unet, scheduler, feature_extractor, image_encoder)
+        self.setup_controlnet(controlnet)
+
+
+class StableDiffusionControlNetPipeline_finetune(_WithControlNet, StableDiffusionPipeline_finetune):
+    """reference model_diffusers.py:418-823: the t2i loop with a ControlNet evaluated on the scaled input of every step"""
+
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, height=None, width=None, num_inference_steps: int = 50, timesteps=None,
+                 guidance_scale: float = 7.5, negative_prompt=None, num_images_per_prompt: int = 1, eta: float = 0.0,
+                 generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None, ip_adapter_image=None,
+                 ip_adapter_image_embeds=None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, guess_mode: bool = False,
+                 control_guidance_start=0.0, control_guidance_end=1.0, guidance_rescale: float = 0.0, clip_skip=0,
+                 region_map_state=None, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), latent_processing=0,
+                 callback_on_step_end=None, image_t2i_adapter=None, long_encode=0, text_input_ids=None, **kwargs):
+        if ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing or timesteps is not None:
+            raise NotImplementedError("raw IP-Adapter images, T2I-Adapter, latent previews and custom timestep lists are "
+                                      "'next' rows (SURVEY.md 8f)")
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        device, text, n_img, added, region_state, ca = self._prepare_call(
+            prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, text_input_ids, guidance_scale,
+            num_images_per_prompt, clip_skip, long_encode, ip_adapter_image_embeds, region_map_state, width, height,
+            cross_attention_kwargs)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        ts = self.scheduler.timesteps
+        control = self._control(image, controlnet_conditioning_scale, control_guidance_start, control_guidance_end, width,
+                                height, len(ts), n_img, num_images_per_prompt)
+        x = self.prepare_latents(n_img, self.unet.config.in_channels, height, width, text.dtype, device, generator, latents)
+        x = x * float(self.scheduler.init_noise_sigma)
+        x = self._denoise(x, ts, text, region_state, weight_func, guidance_scale, guidance_rescale, added, ca,
+                          callback_on_step_end, control=control)
+        return [self.latent_to_image(x, output_type)]
+
+
+class StableDiffusionControlNetImg2ImgPipeline_finetune(_WithControlNet, StableDiffusionImg2ImgPipeline_finetune):
+    """reference model_diffusers.py:826-1225: img2img + ControlNet (`image` = the picture, `control_image` = the condition)"""
+
+
+class StableDiffusionControlNetInpaintPipeline_finetune(_WithControlNet, StableDiffusionInpaintPipeline_finetune):
+    """reference model_diffusers.py:1921-: inpainting + ControlNet"""

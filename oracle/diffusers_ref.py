@@ -39,15 +39,32 @@ def euler_txt2img(sd, cfg, latents, text_rows, region_state, guidance_scale, num
     """latents: unit-variance noise [n_img,4,h,w] (multiplied by init_noise_sigma here, as diffusers' prepare_latents does);
     text_rows [2*n_img,S,ctx] in the row layout [u.., c..]; returns the final latents (fp32)."""
     ts, sigmas, init = euler_schedule(num_inference_steps, timestep_spacing, steps_offset)
-    x = latents.float() * init
-    for i, t in enumerate(ts):
-        sigma, sigma_next = float(sigmas[i]), float(sigmas[i + 1])
+    return euler_run(sd, cfg, latents.float() * init, ts, sigmas, 0, text_rows, region_state, guidance_scale)
+
+
+def euler_run(sd, cfg, x, ts, sigmas, t_start, text_rows, region_state, guidance_scale, after_step=None, controlnet=None):
+    """The loop of reference model_diffusers.py over the timesteps ts[t_start:] (the img2img / inpaint classes truncate the
+    schedule by `strength`): the Euler step uses sigmas[t_start + i], the region bias `scheduler.sigmas[i]` - the LOOP index
+    into the un-truncated schedule, as the reference writes it.  after_step(i, x) -> x: inpainting's
+    re-imposition of the known region; controlnet = {"sd", "cond" [2 n_img rows], "scale": [per step]}: evaluated on the
+    scaled input of every step, no region prompt."""
+    x = x.float()
+    for i, t in enumerate(ts[t_start:]):
+        k = t_start + i
+        sigma, sigma_next = float(sigmas[k]), float(sigmas[k + 1])
         x_in = torch.cat([x] * 2) / ((sigma ** 2 + 1) ** 0.5)
-        rp = {"region_state": region_state, "sigma": sigma, "weight_func": ra.default_weight_func}
-        eps = unet_ref.unet_forward(sd, cfg, x_in, torch.full((x_in.shape[0],), float(t)), text_rows, region_prompt=rp,
-                                    n_std_groups=1)
+        tt = torch.full((x_in.shape[0],), float(t))
+        rp = {"region_state": region_state, "sigma": float(sigmas[i]), "weight_func": ra.default_weight_func}
+        down, mid = None, None
+        if controlnet is not None:
+            down, mid = unet_ref.controlnet_forward(controlnet["sd"], cfg, x_in, tt, text_rows, controlnet["cond"],
+                                                    controlnet["scale"][i])
+        eps = unet_ref.unet_forward(sd, cfg, x_in, tt, text_rows, region_prompt=rp, n_std_groups=1, down_residuals=down,
+                                    mid_residual=mid)
         u, c = eps.chunk(2)
         eps = u + guidance_scale * (c - u)
         pred_original = x - sigma * eps
         x = x + (x - pred_original) / sigma * (sigma_next - sigma)
+        if after_step is not None:
+            x = after_step(i, x)
     return x

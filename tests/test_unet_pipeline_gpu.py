@@ -1064,6 +1064,74 @@ def test_diffusers_scheduler_pipeline_vs_oracle(ops, n_img):
     assert (z - base).abs().max().item() < 5e-3 and (nz - base).abs().max().item() > 1e-3
 
 
+def test_diffusers_img2img_inpaint_controlnet_pipelines(ops):
+    """The other five classes of reference model_diffusers.py (img2img :1228-, inpaint :1515-, ControlNet :418-, ControlNet
+    img2img :826-, ControlNet inpaint :1921-) against the oracle's Euler loop: truncated schedule with the region sigma read at
+    the loop index (quirk q5), add_noise start, post-step re-imposition of the known region, per-step ControlNet."""
+    from oracle import diffusers_ref
+    from diffusionspatialcontrol_amd.modules import model_diffusers as md
+    cfg, unet, sd, text = _tiny_setup(1)
+    state, ids, rs = _region_state(n_img=1)
+    cn, cn_sd = _controlnet(cfg)
+    cn = cn.cuda().eval()
+    pe, ne = text[1:2], text[:1]
+    rows = torch.cat([ne, pe]).float()
+    steps, gs = 6, 1.5
+    ts, sigmas, init = diffusers_ref.euler_schedule(steps)
+    lat0 = (torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(31)) * 0.7).half()
+    ctrl = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(32))
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[..., :64, :] = 1.0
+    m16 = F.interpolate(mask, size=(16, 16))
+    common = dict(num_inference_steps=steps, guidance_scale=gs, output_type="latent", prompt_embeds=pe,
+                  negative_prompt_embeds=ne, region_map_state=state, text_input_ids=ids, height=128, width=128)
+    noise = lambda seed: torch.randn(lat0.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float16).float()  # noqa: E731
+    control = {"sd": cn_sd, "cond": torch.cat([ctrl.half().float()] * 2)}
+
+    def check(out, ref, what):
+        sc = ref.abs().max().item()
+        assert torch.isfinite(out).all() and (out - ref).abs().max().item() < 6e-2 * sc, (what, (out - ref).abs().max().item(), sc)
+
+    # img2img: strength 0.5 -> the last 3 of 6 steps
+    pipe = md.StableDiffusionImg2ImgPipeline_finetune(None, None, FakeTokenizer(), unet, md.EulerDiscreteScheduler())
+    out = pipe(image=lat0.clone(), strength=0.5, generator=torch.Generator().manual_seed(41), **common)[0].float().cpu()
+    t0 = steps - int(steps * 0.5)
+    start = lat0.float() + float(sigmas[t0]) * noise(41)
+    check(out, diffusers_ref.euler_run(sd, cfg, start, ts, sigmas, t0, rows, rs, gs), "img2img")
+    # inpainting, strength 1: pure noise start, known region re-imposed after every step
+    pipe = md.StableDiffusionInpaintPipeline_finetune(None, None, FakeTokenizer(), unet, md.EulerDiscreteScheduler())
+    out = pipe(image=lat0.clone(), mask_image=mask, strength=1.0, generator=torch.Generator().manual_seed(42), **common)[0].float().cpu()
+    n42 = noise(42)
+
+    def keep(i, x):
+        known = lat0.float() + (float(sigmas[i + 1]) * n42 if i < steps - 1 else 0.0)
+        return (1 - m16) * known + m16 * x
+    ref = diffusers_ref.euler_run(sd, cfg, n42 * init, ts, sigmas, 0, rows, rs, gs, after_step=keep)
+    check(out, ref, "inpaint")
+    assert (out * (1 - m16) - lat0.float() * (1 - m16)).abs().max().item() < 2e-2 * lat0.float().abs().max().item()   # known half kept
+    # ControlNet t2i, guidance window [0, 0.5]
+    pipe = md.StableDiffusionControlNetPipeline_finetune(None, None, FakeTokenizer(), unet, cn, md.EulerDiscreteScheduler())
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(43)).half()
+    out = pipe(image=ctrl, latents=lat.clone(), controlnet_conditioning_scale=0.8, control_guidance_end=0.5, **common)[0].float().cpu()
+    keep_s = [0.8 * (1.0 - float((i + 1) / steps > 0.5)) for i in range(steps)]
+    ref = diffusers_ref.euler_run(sd, cfg, lat.float() * init, ts, sigmas, 0, rows, rs, gs, controlnet=dict(control, scale=keep_s))
+    check(out, ref, "controlnet")
+    # ControlNet img2img and ControlNet inpaint: the same pieces combined
+    pipe = md.StableDiffusionControlNetImg2ImgPipeline_finetune(None, None, FakeTokenizer(), unet, cn, md.EulerDiscreteScheduler())
+    out = pipe(image=lat0.clone(), control_image=ctrl, strength=0.5, generator=torch.Generator().manual_seed(44), **common)[0].float().cpu()
+    start = lat0.float() + float(sigmas[t0]) * noise(44)
+    ref = diffusers_ref.euler_run(sd, cfg, start, ts, sigmas, t0, rows, rs, gs, controlnet=dict(control, scale=[1.0] * 3))
+    check(out, ref, "controlnet img2img")
+    pipe = md.StableDiffusionControlNetInpaintPipeline_finetune(None, None, FakeTokenizer(), unet, cn, md.EulerDiscreteScheduler())
+    out = pipe(image=lat0.clone(), mask_image=mask, control_image=ctrl, generator=torch.Generator().manual_seed(42), **common)[0].float().cpu()
+    ref = diffusers_ref.euler_run(sd, cfg, n42 * init, ts, sigmas, 0, rows, rs, gs, after_step=keep,
+                                  controlnet=dict(control, scale=[1.0] * steps))
+    check(out, ref, "controlnet inpaint")
+    with pytest.raises(ValueError):
+        md.StableDiffusionControlNetImg2ImgPipeline_finetune(None, None, FakeTokenizer(), unet, cn, md.EulerDiscreteScheduler())(
+            image=lat0.clone(), strength=0.5, **common)                       # control_image missing
+
+
 def test_prompt_string_pipeline(ops):
     """`txt2img(prompt=..., negative_prompt=...)` through the A1111-style encoder (emphasis, BREAK,
     75-token chunks) on a fake tokenizer / text encoder == the same call with the embeddings and token ids passed in;
