@@ -71,6 +71,7 @@ class StableDiffusionPipeline:
         self.unet, self.scheduler = unet, scheduler
         self.feature_extractor, self.image_encoder = feature_extractor, image_encoder
         self.controlnet = None
+        self.adapter = None                                  # T2I-Adapter, set by modules.t2i_adapter.setup_model_t2i_adapter
         self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
         self._do_classifier_free_guidance = True
         self._graphs = {}
@@ -193,6 +194,41 @@ class StableDiffusionPipeline:
                 mid = torch.cat([torch.zeros_like(mid), mid])
             return {"down_block_additional_residuals": down, "mid_block_additional_residual": mid}
         return hook
+
+    def _adapter_hook(self, image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height,
+                      steps_denoising, num_images_per_prompt):
+        """T2I-Adapter (reference :700-703, :722-731): the adapter's features are computed once; every model call during the
+        first int(steps_denoising * factor) distinct sigmas hands clones of them to the UNet as
+        `down_intrablock_additional_residuals`.  None when no adapter image is given."""
+        if image_t2i_adapter is None:
+            return None
+        if getattr(self, "adapter", None) is None:
+            raise ValueError("image_t2i_adapter needs an adapter: modules.t2i_adapter.setup_model_t2i_adapter(pipe, adapter)")
+        from .t2i_adapter import preprocessing_t2i_adapter
+        state = preprocessing_t2i_adapter(self, image_t2i_adapter, width, height, adapter_conditioning_scale, num_images_per_prompt)
+        seen = []
+        limit = int(steps_denoising * adapter_conditioning_factor)
+
+        def hook(latent_model_input, sigma):
+            use = len(seen) < limit
+            key = float(sigma[0])
+            if key not in seen:
+                seen.append(key)
+            return {"down_intrablock_additional_residuals": [v.clone() for v in state]} if use else {}
+        return hook
+
+    @staticmethod
+    def _merge_hooks(*hooks):
+        hooks = [h for h in hooks if h is not None]
+        if not hooks:
+            return None
+
+        def merged(latent_model_input, sigma):
+            out = {}
+            for h in hooks:
+                out.update(h(latent_model_input, sigma))
+            return out
+        return merged
 
     def get_sigmas(self, steps, params):
         """reference :848-882"""
@@ -331,20 +367,40 @@ class StableDiffusionPipeline:
     def txt2img(self, prompt: Union[str, List[str], None] = None, height: int = 512, width: int = 512,
                 num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None, eta: float = 0.0,
                 generator: Optional[torch.Generator] = None, latents: Optional[torch.Tensor] = None,
-                output_type: Optional[str] = "pil", callback_steps: Optional[int] = 1, upscale=False,
-                region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
+                output_type: Optional[str] = "pil", callback_steps: Optional[int] = 1, upscale=False, upscale_x: float = 2.0,
+                upscale_method: str = "bicubic", upscale_antialias: bool = False, upscale_denoising_strength: float = 0.7,
+                region_map_state=None, sampler_name="", sampler_opt={}, sampler_name_hires="", sampler_opt_hires={},
+                start_time=-1, timeout=180,
                 latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), seed=0,
                 ip_adapter_image=None, control_img=None, controlnet_conditioning_scale=None, control_guidance_start=None,
-                control_guidance_end=None, image_t2i_adapter=None, guidance_rescale: float = 0.0,
+                control_guidance_end=None, image_t2i_adapter=None, adapter_conditioning_scale=1.0,
+                adapter_conditioning_factor: float = 1.0, guidance_rescale: float = 0.0,
                 cross_attention_kwargs=None, clip_skip=None, long_encode=0, num_images_per_prompt=1,
                 ip_adapter_image_embeds=None,
                 # build-specific inputs (the prompt encoders are a "next" row):
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                 text_input_ids=None, fused: Optional[bool] = None, **unsupported):
-        if upscale or ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images (CLIP image encoder) / "
-                                      "T2I-Adapter / latent previews are outside the denoising hot path built here "
+        if ip_adapter_image is not None or latent_processing:
+            raise NotImplementedError("IP-Adapter from raw images (CLIP image encoder) / "
+                                      "latent previews are outside the denoising hot path built here "
                                       "(SURVEY.md 8f); pass ip_adapter_image_embeds for IP-Adapter")
+        hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                     negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
+                     sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
+                     region_map_state=region_map_state, seed=seed, control_img=control_img,
+                     controlnet_conditioning_scale=controlnet_conditioning_scale, control_guidance_start=control_guidance_start,
+                     control_guidance_end=control_guidance_end, image_t2i_adapter=image_t2i_adapter,
+                     adapter_conditioning_scale=adapter_conditioning_scale, adapter_conditioning_factor=adapter_conditioning_factor,
+                     guidance_rescale=guidance_rescale, cross_attention_kwargs=cross_attention_kwargs, clip_skip=clip_skip,
+                     long_encode=long_encode, num_images_per_prompt=num_images_per_prompt, weight_func=weight_func,
+                     ip_adapter_image_embeds=ip_adapter_image_embeds, prompt_embeds=prompt_embeds,
+                     negative_prompt_embeds=negative_prompt_embeds, text_input_ids=text_input_ids, output_type=output_type,
+                     start_time=start_time, timeout=timeout) if upscale else None
+        if image_t2i_adapter is not None:
+            if getattr(self, "adapter", None) is None:
+                raise ValueError("image_t2i_adapter needs an adapter: modules.t2i_adapter.setup_model_t2i_adapter(pipe, adapter)")
+            from .t2i_adapter import default_height_width
+            height, width = default_height_width(self, height, width, image_t2i_adapter)              # :990-991
         sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
         device = self._execution_device
         self._do_classifier_free_guidance = guidance_scale > 1.0
@@ -381,6 +437,9 @@ class StableDiffusionPipeline:
         control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
                                              control_guidance_end, width, height, num_inference_steps, n_img,
                                              num_images_per_prompt, text)                                    # :1060-1061
+        control_hook = self._merge_hooks(control_hook, self._adapter_hook(
+            image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height, len(sigmas),
+            num_images_per_prompt))                                                                         # :1086-1089
         if fused is None:
             fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg and not self.v_prediction \
                 and control_hook is None
@@ -394,6 +453,8 @@ class StableDiffusionPipeline:
                                              guidance_rescale, n_img, cross_attention_kwargs, eta,
                                              num_inference_steps, sampler_opt, seed, start_time, timeout,
                                              control_hook=control_hook)
+        if upscale:                                                                                          # :1176-1228
+            return self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
         return [self.latent_to_image(latents, output_type)]
 
     def get_sampler_extra_args_i2i(self, sigmas, steps, sampler_opt, latents, seed, func):
@@ -495,14 +556,28 @@ class StableDiffusionPipeline:
         gdev = generator.device if generator is not None else device
         return torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
 
+    def _hires_pass(self, latents, height, width, upscale_x, upscale_method, upscale_antialias, **img2img_kwargs):
+        """reference :1176-1228 (txt2img), :789-838 (img2img), :1705-1757 (inpaiting): interpolate the final latents by
+        `upscale_x` and run img2img on them at `upscale_denoising_strength`"""
+        f = self.vae_scale_factor
+        target_height = int(height * upscale_x // f) * 8
+        target_width = int(width * upscale_x // f) * 8
+        latents = torch.nn.functional.interpolate(latents.float(), size=(int(target_height // f), int(target_width // f)),
+                                                  mode=upscale_method,
+                                                  **({"antialias": upscale_antialias} if upscale_method in ("bilinear", "bicubic") else {})
+                                                  ).to(latents.dtype)
+        return self.img2img(latents=latents, width=int(target_width), height=int(target_height), **img2img_kwargs)
+
     @torch.no_grad()
     def img2img(self, prompt=None, num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None,
                 generator: Optional[torch.Generator] = None, image=None, output_type: Optional[str] = "pil", latents=None,
                 strength=1.0, region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
                 scale_ratio=8.0, latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), upscale=False,
+                upscale_x: float = 2.0, upscale_method: str = "bicubic", upscale_antialias: bool = False,
+                upscale_denoising_strength: float = 0.7, sampler_name_hires="", sampler_opt_hires={},
                 width=None, height=None, seed=0, ip_adapter_image=None, control_img=None,
                 controlnet_conditioning_scale=None, control_guidance_start=None, control_guidance_end=None,
-                image_t2i_adapter=None,
+                image_t2i_adapter=None, adapter_conditioning_scale=1.0, adapter_conditioning_factor: float = 1.0,
                 guidance_rescale: float = 0.0, cross_attention_kwargs=None, clip_skip=None, long_encode=0,
                 num_images_per_prompt=1, ip_adapter_image_embeds=None,
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
@@ -510,9 +585,21 @@ class StableDiffusionPipeline:
         """reference :543-846: encode the image (or take `latents`), keep the last `strength` fraction of the schedule, add
         noise, denoise.  Reproduces the reference's start: `latents + noise * sqrt(sigma_0^2 + 1)` (:647 - sic, not
         `noise * sigma_0`)."""
-        if upscale or ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images / T2I-Adapter / latent "
+        if ip_adapter_image is not None or latent_processing:
+            raise NotImplementedError("IP-Adapter from raw images / latent "
                                       "previews are outside the denoising hot path built here (SURVEY.md 8f)")
+        hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+                     negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
+                     sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
+                     region_map_state=region_map_state, seed=seed, control_img=control_img,
+                     controlnet_conditioning_scale=controlnet_conditioning_scale, control_guidance_start=control_guidance_start,
+                     control_guidance_end=control_guidance_end, image_t2i_adapter=image_t2i_adapter,
+                     adapter_conditioning_scale=adapter_conditioning_scale, adapter_conditioning_factor=adapter_conditioning_factor,
+                     guidance_rescale=guidance_rescale, cross_attention_kwargs=cross_attention_kwargs, clip_skip=clip_skip,
+                     long_encode=long_encode, num_images_per_prompt=num_images_per_prompt, weight_func=weight_func,
+                     ip_adapter_image_embeds=ip_adapter_image_embeds, prompt_embeds=prompt_embeds,
+                     negative_prompt_embeds=negative_prompt_embeds, text_input_ids=text_input_ids, output_type=output_type,
+                     start_time=start_time, timeout=timeout) if upscale else None
         sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
         device = self._execution_device
         if image is not None:
@@ -548,6 +635,9 @@ class StableDiffusionPipeline:
         control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
                                              control_guidance_end, width, height, len(sigma_sched), n_img,
                                              num_images_per_prompt, text)                                    # :675-676
+        control_hook = self._merge_hooks(control_hook, self._adapter_hook(
+            image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height, len(sigma_sched),
+            num_images_per_prompt))                                                                         # :700-703
         if fused is None:
             fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and self.do_classifier_free_guidance \
                 and not self.v_prediction and control_hook is None
@@ -562,6 +652,8 @@ class StableDiffusionPipeline:
                                              guidance_rescale, n_img, cross_attention_kwargs, 0.0, len(sigma_sched),
                                              sampler_opt, seed, start_time, timeout, sampler_args=args,
                                              control_hook=control_hook)
+        if upscale:                                                                                          # :789-838
+            return self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
         return [self.latent_to_image(latents, output_type)]
 
     def _sigma_to_alpha_sigma_t(self, sigma):
@@ -608,7 +700,8 @@ class StableDiffusionPipeline:
                   region_map_state=None, sampler_name="", sampler_opt={}, start_time=-1, timeout=180,
                   latent_processing=0, weight_func=lambda w, sigma, qk: w * sigma * qk.std(), seed=0,
                   ip_adapter_image=None, control_img=None, controlnet_conditioning_scale=None, control_guidance_start=None,
-                  control_guidance_end=None, image_t2i_adapter=None, image=None, mask_image=None,
+                  control_guidance_end=None, image_t2i_adapter=None, adapter_conditioning_scale=1.0,
+                  adapter_conditioning_factor: float = 1.0, image=None, mask_image=None,
                   masked_image_latents=None, padding_mask_crop=None, strength: float = 1.0, guidance_rescale: float = 0.0,
                   cross_attention_kwargs=None, clip_skip=None, long_encode=0, num_images_per_prompt=1,
                   ip_adapter_image_embeds=None,
@@ -617,9 +710,8 @@ class StableDiffusionPipeline:
         """reference :1365-1760 (method name as spelled there), the 4-channel UNet branch: the known region
         `image_latents + sigma * noise` is re-imposed on the model input before every model call after the first
         (:1599-1612).  Protocol mode only (the blend is a hook on the model input)."""
-        if upscale or ip_adapter_image is not None or image_t2i_adapter is not None or latent_processing \
-                or padding_mask_crop is not None:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images / T2I-Adapter / latent "
+        if upscale or ip_adapter_image is not None or latent_processing or padding_mask_crop is not None:
+            raise NotImplementedError("hires upscale / IP-Adapter from raw images / latent "
                                       "previews / mask cropping are outside the denoising hot path built here")
         if self.unet.config.in_channels != 4:
             raise NotImplementedError("the 9-channel inpainting UNet (mask + masked-image latents concatenated to the "
@@ -671,6 +763,9 @@ class StableDiffusionPipeline:
         control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
                                              control_guidance_end, width, height, num_inference_steps, n_img,
                                              num_images_per_prompt, text)                                    # :1577-1578
+        control_hook = self._merge_hooks(control_hook, self._adapter_hook(
+            image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height, len(sigmas),
+            num_images_per_prompt))                                                                         # :1588-1591
         latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                          guidance_rescale, n_img, cross_attention_kwargs, eta, num_inference_steps,
                                          sampler_opt, seed, start_time, timeout, input_hook=keep_known_region,

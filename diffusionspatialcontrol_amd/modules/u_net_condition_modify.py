@@ -546,17 +546,26 @@ class _EncoderHalf:
             return ops.conv3x3_fewcin(sample, wt, ci.bias, ci.out_channels)   # NCHW latents -> NHWC features, one launch
         return ci(sample.contiguous()).contiguous(memory_format=torch.channels_last)
 
-    def _run_down(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs):
+    def _run_down(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs, intrablock=None):
+        """intrablock: T2I-Adapter features, one per down block (reference :1194-1230): added after the LAST resnet /
+        attention pair of a cross-attention block (so the skip tensor carries it), after the whole block otherwise"""
+        intrablock = None if intrablock is None else list(intrablock)
         skips = [x]
         for blk in self.down_blocks:
+            extra = intrablock.pop(0) if intrablock else None
+            last = len(blk.resnets) - 1
             for j, res in enumerate(blk.resnets):
                 x = res(x, temb_act, tadd[res])
                 if blk.has_attn:
                     x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
+                    if j == last and extra is not None:
+                        x = x + extra.to(x.dtype)
                 skips.append(x)
             if hasattr(blk, "downsamplers"):
                 x = blk.downsamplers[0](x)
                 skips.append(x)
+            if not blk.has_attn and extra is not None:
+                x = x + extra.to(x.dtype)
         return skips, x
 
     def _run_mid(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs):
@@ -673,7 +682,12 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
             encoder_hidden_states = (encoder_hidden_states, self.encoder_hid_proj(added_cond_kwargs.get("image_embeds")))
         x = self._conv_in(sample)
         tadd = self._all_temb_adds(temb_act)
-        skips, x = self._run_down(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
+        if down_intrablock_additional_residuals is None and mid_block_additional_residual is None \
+                and down_block_additional_residuals is not None:
+            # legacy T2I-Adapter usage (reference :1200-1211): residuals without a mid residual are intra-block ones
+            down_intrablock_additional_residuals, down_block_additional_residuals = down_block_additional_residuals, None
+        skips, x = self._run_down(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs,
+                                  intrablock=down_intrablock_additional_residuals)
         if down_block_additional_residuals is not None:          # ControlNet hook (reference :1236-1245)
             skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
         x = self._run_mid(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)

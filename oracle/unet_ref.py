@@ -84,8 +84,31 @@ def _transformer(sd, pre, x, enc, heads, groups, region_prompt, n_std_groups):
     return x + res
 
 
-def _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups, add_to_conv_in=None):
-    """time embedding, conv_in (+ an optional additive term: ControlNet's conditioning embedding), down blocks, mid block"""
+def t2i_adapter_forward(sd, image, downscale_factor=8):
+    """diffusers 0.27.2 `T2IAdapter` (full_adapter; un-vendored, restated from the published structure - parity unpinned):
+    pixel-unshuffle, conv_in, four blocks of [2x2 average pool (ceil), 1x1 in_conv when the width changes, ResNets of
+    3x3 conv -> ReLU -> 1x1 conv + skip]; returns the four feature maps."""
+    sd = {k: v.float() for k, v in sd.items()}
+    x = _conv(sd, "adapter.conv_in", F.pixel_unshuffle(image.float(), downscale_factor))
+    feats, i = [], 0
+    while f"adapter.body.{i}.resnets.0.block1.weight" in sd:
+        if i > 0:
+            x = F.avg_pool2d(x, 2, 2, ceil_mode=True)
+        if f"adapter.body.{i}.in_conv.weight" in sd:
+            x = _conv(sd, f"adapter.body.{i}.in_conv", x, padding=0)
+        j = 0
+        while f"adapter.body.{i}.resnets.{j}.block1.weight" in sd:
+            pre = f"adapter.body.{i}.resnets.{j}"
+            x = x + _conv(sd, pre + ".block2", F.relu(_conv(sd, pre + ".block1", x)), padding=0)
+            j += 1
+        feats.append(x)
+        i += 1
+    return feats
+
+
+def _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups, add_to_conv_in=None, intrablock=None):
+    """time embedding, conv_in (+ an optional additive term: ControlNet's conditioning embedding), down blocks, mid block.
+    intrablock: T2I-Adapter features, one per down block (reference u_net_condition_modify.py:1194-1230)"""
     ch, heads_l, G, eps = cfg.block_out_channels, cfg.num_attention_heads, cfg.norm_num_groups, cfg.norm_eps
     half = ch[0] // 2
     freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
@@ -96,17 +119,24 @@ def _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups, a
     if add_to_conv_in is not None:
         x = x + add_to_conv_in
     skips = [x]
+    intrablock = None if intrablock is None else list(intrablock)
     for i in range(len(ch)):
+        extra = intrablock.pop(0) if intrablock else None
+        has_attn = f"down_blocks.{i}.attentions.0.norm.weight" in sd
         j = 0
         while f"down_blocks.{i}.resnets.{j}.norm1.weight" in sd:
             x = _resnet(sd, f"down_blocks.{i}.resnets.{j}", x, temb, G, eps)
-            if f"down_blocks.{i}.attentions.{j}.norm.weight" in sd:
+            if has_attn:
                 x = _transformer(sd, f"down_blocks.{i}.attentions.{j}", x, enc, heads_l[i], G, region_prompt, n_std_groups)
+                if extra is not None and f"down_blocks.{i}.resnets.{j + 1}.norm1.weight" not in sd:
+                    x = x + extra                                   # after the block's last resnet / attention pair
             skips.append(x)
             j += 1
         if f"down_blocks.{i}.downsamplers.0.conv.weight" in sd:
             x = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
             skips.append(x)
+        if extra is not None and not has_attn:
+            x = x + extra                                           # block without attention: after the whole block
     x = _resnet(sd, "mid_block.resnets.0", x, temb, G, eps)
     if "mid_block.attentions.0.norm.weight" in sd:
         x = _transformer(sd, "mid_block.attentions.0", x, enc, heads_l[-1], G, region_prompt, n_std_groups)
@@ -136,13 +166,14 @@ def controlnet_forward(sd, cfg, sample, timestep, enc, controlnet_cond, conditio
     return [d * conditioning_scale for d in down], mid * conditioning_scale
 
 
-def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_groups=1, down_residuals=None, mid_residual=None):
+def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_groups=1, down_residuals=None, mid_residual=None,
+                 intrablock=None):
     """cfg: any object with block_out_channels, num_attention_heads, norm_num_groups, norm_eps.  down_residuals /
     mid_residual: the ControlNet hooks of reference u_net_condition_modify.py:1236-1245,1269-1270."""
     sd = {k: v.float() for k, v in sd.items()}
     ch, heads_l, G, eps = cfg.block_out_channels, cfg.num_attention_heads, cfg.norm_num_groups, cfg.norm_eps
     enc = enc.float()
-    temb, skips, x = _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups)
+    temb, skips, x = _encoder_half(sd, cfg, sample, timestep, enc, region_prompt, n_std_groups, intrablock=intrablock)
     if down_residuals is not None:
         skips = [s_ + r for s_, r in zip(skips, down_residuals)]
     if mid_residual is not None:
@@ -161,7 +192,7 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
 
 
 def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None,
-                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False, controlnet=None):
+                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False, controlnet=None, adapter=None):
     """txt2img's loop for n_img images in the row layout [u_0.., c_0..]; returns the final latents (fp32).
 
     latents: initial noise ALREADY multiplied by sqrt(sigma_0^2 + 1) (model_k_diffusion.py:1043);
@@ -176,6 +207,7 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
 
     calls = [0]
     seen_sigmas = []
+    adapter_seen = []
 
     def model_fn(x, sigma):
         if input_hook is not None:                     # inpainting: the known region re-imposed on the model input (:1599-1612)
@@ -195,8 +227,16 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
                 scale = controlnet["scale"][len(seen_sigmas) - 1]
                 down, mid = controlnet_forward(controlnet["sd"], cfg, inp / ((sigma[0] ** 2 + 1) ** 0.5), t, text,
                                                controlnet["cond"], scale, controlnet.get("guess_mode", False))
+            intra = None
+            if adapter is not None:
+                # {"state": features duplicated for CFG, "limit": int(len(sigmas) * factor)}: used while fewer than `limit`
+                # distinct sigmas have been seen BEFORE this call (model_k_diffusion.py:1109-1117)
+                if len(adapter_seen) < adapter["limit"]:
+                    intra = adapter["state"]
+                if float(sigma[0]) not in adapter_seen:
+                    adapter_seen.append(float(sigma[0]))
             return unet_forward(sd, cfg, xin, t, text, region_prompt=None if v_prediction else rp, n_std_groups=n_img,
-                                down_residuals=down, mid_residual=mid)
+                                down_residuals=down, mid_residual=mid, intrablock=intra)
 
         out = den.forward(eps_fn, inp, torch.cat([sigma] * 2))
         return kd.cfg_combine(out, guidance_scale)                                    # :1162-1166
