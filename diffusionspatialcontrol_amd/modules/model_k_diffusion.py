@@ -344,13 +344,46 @@ class StableDiffusionPipeline:
         self.unet.set_attn_processor(AttnProcessor())
         self._graphs = {}
 
+    def encode_image(self, image, device, num_images_per_prompt, output_hidden_states=None):
+        """reference :148-170: CLIP image embeddings (or penultimate hidden states) of the IP-Adapter image and their
+        unconditional counterpart; `image_encoder` is any transformers-style CLIPVisionModelWithProjection, `feature_extractor`
+        its image processor"""
+        if self.image_encoder is None:
+            raise NotImplementedError("ip_adapter_image needs the pipeline's image_encoder (a CLIP vision model with "
+                                      "projection) and feature_extractor; or pass ip_adapter_image_embeds")
+        dtype = next(self.image_encoder.parameters()).dtype
+        if not isinstance(image, torch.Tensor):
+            image = self.feature_extractor(image, return_tensors="pt").pixel_values
+        image = image.to(device=device, dtype=dtype)
+        if output_hidden_states:
+            pos = self.image_encoder(image, output_hidden_states=True).hidden_states[-2]
+            neg = self.image_encoder(torch.zeros_like(image), output_hidden_states=True).hidden_states[-2]
+            return pos.repeat_interleave(num_images_per_prompt, dim=0), neg.repeat_interleave(num_images_per_prompt, dim=0)
+        emb = self.image_encoder(image).image_embeds.repeat_interleave(num_images_per_prompt, dim=0)
+        return emb, torch.zeros_like(emb)
+
     def prepare_ip_adapter_image_embeds(self, ip_adapter_image, ip_adapter_image_embeds, device, num_images_per_prompt,
                                         do_classifier_free_guidance):
         """Reference :173-222, pre-computed-embeddings branch (:203-221): each list entry holds [negative; positive]
         along dim 0 when CFG is on; both halves are repeated per image and re-concatenated."""
-        if ip_adapter_image_embeds is None:
-            raise NotImplementedError("encoding ip_adapter_image needs the CLIP image encoder (a 'next' row): pass "
-                                      "ip_adapter_image_embeds")
+        if ip_adapter_image_embeds is None:                                                       # :176-201
+            if not isinstance(ip_adapter_image, list):
+                ip_adapter_image = [ip_adapter_image]
+            layers = self.unet.encoder_hid_proj.image_projection_layers
+            if len(ip_adapter_image) != len(layers):
+                raise ValueError(f"`ip_adapter_image` must have same length as the number of IP Adapters. Got "
+                                 f"{len(ip_adapter_image)} images and {len(layers)} IP Adapters.")
+            from .u_net_condition_modify import ImageProjection
+            out = []
+            for img, layer in zip(ip_adapter_image, layers):
+                hidden = not isinstance(layer, ImageProjection)            # Plus-style projections take hidden states
+                pos, neg = self.encode_image(img, device, 1, hidden)
+                pos = torch.stack([pos] * num_images_per_prompt, dim=0)
+                neg = torch.stack([neg] * num_images_per_prompt, dim=0)
+                if do_classifier_free_guidance:
+                    pos = torch.cat([neg, pos]).to(device)
+                out.append(pos)
+            return out
         out = []
         for e in ip_adapter_image_embeds:
             ones = [1] * (e.dim() - 1)
@@ -380,10 +413,8 @@ class StableDiffusionPipeline:
                 # build-specific inputs (the prompt encoders are a "next" row):
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                 text_input_ids=None, fused: Optional[bool] = None, **unsupported):
-        if ip_adapter_image is not None or latent_processing:
-            raise NotImplementedError("IP-Adapter from raw images (CLIP image encoder) / "
-                                      "latent previews are outside the denoising hot path built here "
-                                      "(SURVEY.md 8f); pass ip_adapter_image_embeds for IP-Adapter")
+        if latent_processing:
+            raise NotImplementedError("latent previews are outside the denoising hot path built here (SURVEY.md 8f)")
         hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                      negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
                      sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
@@ -430,8 +461,9 @@ class StableDiffusionPipeline:
                                          num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)  # :1050
         cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
         added_cond_kwargs = None
-        if ip_adapter_image_embeds is not None:                                                              # :1069-1082
-            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt, cfg)
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None:                               # :1069-1082
+            embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, ip_adapter_image_embeds, device,
+                                                          num_images_per_prompt, cfg)
             added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
         self._added_cond_kwargs = added_cond_kwargs
         control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
@@ -585,9 +617,8 @@ class StableDiffusionPipeline:
         """reference :543-846: encode the image (or take `latents`), keep the last `strength` fraction of the schedule, add
         noise, denoise.  Reproduces the reference's start: `latents + noise * sqrt(sigma_0^2 + 1)` (:647 - sic, not
         `noise * sigma_0`)."""
-        if ip_adapter_image is not None or latent_processing:
-            raise NotImplementedError("IP-Adapter from raw images / latent "
-                                      "previews are outside the denoising hot path built here (SURVEY.md 8f)")
+        if latent_processing:
+            raise NotImplementedError("latent previews are outside the denoising hot path built here (SURVEY.md 8f)")
         hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                      negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
                      sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
@@ -628,9 +659,9 @@ class StableDiffusionPipeline:
                                          num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)
         cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
         self._added_cond_kwargs = None
-        if ip_adapter_image_embeds is not None:
-            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt,
-                                                          self.do_classifier_free_guidance)
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
+            embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, ip_adapter_image_embeds, device,
+                                                          num_images_per_prompt, self.do_classifier_free_guidance)
             self._added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
         control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
                                              control_guidance_end, width, height, len(sigma_sched), n_img,
@@ -710,9 +741,9 @@ class StableDiffusionPipeline:
         """reference :1365-1760 (method name as spelled there), the 4-channel UNet branch: the known region
         `image_latents + sigma * noise` is re-imposed on the model input before every model call after the first
         (:1599-1612).  Protocol mode only (the blend is a hook on the model input)."""
-        if upscale or ip_adapter_image is not None or latent_processing or padding_mask_crop is not None:
-            raise NotImplementedError("hires upscale / IP-Adapter from raw images / latent "
-                                      "previews / mask cropping are outside the denoising hot path built here")
+        if upscale or latent_processing or padding_mask_crop is not None:
+            raise NotImplementedError("hires upscale / latent previews / mask cropping are outside the denoising hot path "
+                                      "built here")
         if self.unet.config.in_channels != 4:
             raise NotImplementedError("the 9-channel inpainting UNet (mask + masked-image latents concatenated to the "
                                       "input) is a 'next' row: the few-channel conv_in kernel takes <= 8 input channels")
@@ -743,9 +774,9 @@ class StableDiffusionPipeline:
                                          num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)
         cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
         self._added_cond_kwargs = None
-        if ip_adapter_image_embeds is not None:
-            embeds = self.prepare_ip_adapter_image_embeds(None, ip_adapter_image_embeds, device, num_images_per_prompt,
-                                                          self.do_classifier_free_guidance)
+        if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
+            embeds = self.prepare_ip_adapter_image_embeds(ip_adapter_image, ip_adapter_image_embeds, device,
+                                                          num_images_per_prompt, self.do_classifier_free_guidance)
             self._added_cond_kwargs = {"image_embeds": [e.to(device=device, dtype=text.dtype) for e in embeds]}
         sig_last = float(sigmas[-1])
 
