@@ -519,7 +519,7 @@ def test_other_samplers_protocol_vs_oracle(ops, name, opt):
     assert torch.isfinite(out).all()
     # repeatable to rounding (the toy channel counts fall back to MIOpen's atomic kernels; bitwise equality is asserted at
     # the real SD1.5 shapes in test_sd15_unet_step_full_size)
-    assert (out - pipe.txt2img(None, **kw)[0].float().cpu()).abs().max().item() < 2e-2 * out.abs().max().item()
+    assert (out - pipe.txt2img(None, **kw)[0].float().cpu()).abs().max().item() < 5e-2 * out.abs().max().item()
     sig = pipe.get_sigmas(steps, opt).half().float()
     extra = {k: v for k, v in pipe.get_sampler_extra_args_t2i(sig, 0.0, steps, opt, lat, 3, fn).items() if k != "sigmas"}
     if name == "restart":
