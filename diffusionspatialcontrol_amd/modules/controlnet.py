@@ -94,14 +94,22 @@ class ControlNetModel(_EncoderHalf, nn.Module):
             self._cond_cache = (key, emb.contiguous(memory_format=torch.channels_last), controlnet_cond)
         return self._cond_cache[1]
 
+    def conditioning_embedding(self, controlnet_cond):
+        """channels-last conditioning embedding of a control image (what forward() adds to conv_in's output)"""
+        self._to_channels_last_once()
+        return self._cond_embedding(controlnet_cond)
+
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale: float = 1.0,
                 class_labels=None, timestep_cond=None, attention_mask=None, added_cond_kwargs=None,
-                cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = True):
+                cross_attention_kwargs=None, guess_mode: bool = False, return_dict: bool = True, cond_embedding=None):
+        """cond_embedding: the conditioning embedding computed beforehand (`conditioning_embedding(image)`) - the pipeline's
+        captured step graph keeps it in a static buffer instead of re-running the eight convolutions in every replay;
+        conditioning_scale may be a 0-dim device tensor there (the per-step value is written into it between replays)."""
         if attention_mask is not None:
             raise NotImplementedError("attention masks are not on the hot path (never passed by app.py)")
         temb_act = self._time_act(sample, timestep)
         self._to_channels_last_once()
-        x = self._conv_in(sample) + self._cond_embedding(controlnet_cond)
+        x = self._conv_in(sample) + (self._cond_embedding(controlnet_cond) if cond_embedding is None else cond_embedding)
         tadd = self._all_temb_adds(temb_act)
         skips, x = self._run_down(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
         x = self._run_mid(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
@@ -135,11 +143,12 @@ class MultiControlNetModel(nn.Module):
 
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale, class_labels=None,
                 timestep_cond=None, attention_mask=None, added_cond_kwargs=None, cross_attention_kwargs=None,
-                guess_mode: bool = False, return_dict: bool = True):
+                guess_mode: bool = False, return_dict: bool = True, cond_embedding=None):
         down_sum, mid_sum = None, None
-        for image, scale, net in zip(controlnet_cond, conditioning_scale, self.nets):
+        embs = [None] * len(self.nets) if cond_embedding is None else cond_embedding
+        for image, scale, net, emb in zip(controlnet_cond, conditioning_scale, self.nets, embs):
             down, mid = net(sample, timestep, encoder_hidden_states, image, scale, guess_mode=guess_mode, return_dict=False,
-                            cross_attention_kwargs=cross_attention_kwargs)
+                            cross_attention_kwargs=cross_attention_kwargs, cond_embedding=emb)
             if down_sum is None:
                 down_sum, mid_sum = down, mid
             else:

@@ -177,15 +177,17 @@ class StableDiffusionPipeline:
         kdm = self.k_diffusion_model
         cfg = self.do_classifier_free_guidance
 
-        def hook(latent_model_input, sigma):
-            key = float(sigma[0])                               # one control step per DISTINCT sigma, in call order (:1119-1123)
-            if key not in seen:
+        def schedule(key):
+            """conditioning scale(s) of the model call at sigma `key`: one control step per DISTINCT sigma, in call order"""
+            if key not in seen:                                 # (:1119-1123)
                 seen.append(key)
             k = keep[min(len(seen) - 1, len(keep) - 1)]
             if isinstance(k, list):
-                cond_scale = [c * s_ for c, s_ in zip(scale, k)]
-            else:
-                cond_scale = (scale[0] if isinstance(scale, list) else scale) * k
+                return [c * s_ for c, s_ in zip(scale, k)]
+            return (scale[0] if isinstance(scale, list) else scale) * k
+
+        def hook(latent_model_input, sigma):
+            cond_scale = schedule(float(sigma[0]))
             down, mid = self.controlnet(latent_model_input / ((sigma[0] ** 2 + 1) ** 0.5), kdm.sigma_to_t(sigma),
                                         encoder_hidden_states=text, controlnet_cond=img, conditioning_scale=cond_scale,
                                         guess_mode=guess_mode, return_dict=False)
@@ -193,6 +195,7 @@ class StableDiffusionPipeline:
                 down = [torch.cat([torch.zeros_like(d), d]) for d in down]
                 mid = torch.cat([torch.zeros_like(mid), mid])
             return {"down_block_additional_residuals": down, "mid_block_additional_residual": mid}
+        hook.static = None if guess_mode else {"kind": "controlnet", "image": img, "schedule": schedule}
         return hook
 
     def _adapter_hook(self, image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height,
@@ -209,12 +212,15 @@ class StableDiffusionPipeline:
         seen = []
         limit = int(steps_denoising * adapter_conditioning_factor)
 
-        def hook(latent_model_input, sigma):
+        def schedule(key):
             use = len(seen) < limit
-            key = float(sigma[0])
             if key not in seen:
                 seen.append(key)
-            return {"down_intrablock_additional_residuals": [v.clone() for v in state]} if use else {}
+            return use
+
+        def hook(latent_model_input, sigma):
+            return {"down_intrablock_additional_residuals": [v.clone() for v in state]} if schedule(float(sigma[0])) else {}
+        hook.static = {"kind": "adapter", "state": state, "schedule": schedule}
         return hook
 
     @staticmethod
@@ -228,6 +234,8 @@ class StableDiffusionPipeline:
             for h in hooks:
                 out.update(h(latent_model_input, sigma))
             return out
+        statics = [getattr(h, "static", None) for h in hooks]
+        merged.static = None if any(st_ is None for st_ in statics) else statics
         return merged
 
     def get_sigmas(self, steps, params):
@@ -813,6 +821,55 @@ class StableDiffusionPipeline:
         cfg = self.do_classifier_free_guidance
         kdm = self.k_diffusion_model
         calls = [0]
+        # Graph-backed model calls: when nothing has to enter the UNet per call besides (x, sigma) - no ControlNet / adapter
+        # residuals, eps-prediction, CFG without rescale, fp16 - the sampler's model call is: one launch that writes the
+        # static inputs, ONE replay of the captured UNet step (the fused mode's graph), one launch for CFG + eps -> denoised.
+        # Every sampler then runs at graph speed; only its own update arithmetic stays eager.
+        control = None if control_hook is None else getattr(control_hook, "static", None)
+        use_graph = (ops.PROTOCOL_GRAPH and (control_hook is None or control is not None) and cfg and guidance_rescale == 0.0
+                     and not self.v_prediction and latents.is_cuda and text.dtype == torch.float16
+                     and self._added_cond_kwargs is None and latents.numel() // latents.shape[0] % 8 == 0)
+        if use_graph:
+            levels = tuple(sorted((int(L), tuple(w.shape)) for L, w in region_state.items())) \
+                if isinstance(region_state, dict) else None
+            ckey = None if control is None else tuple(
+                ("cn", id(self.controlnet), tuple(tuple(i.shape) for i in (p["image"] if isinstance(p["image"], list) else [p["image"]])))
+                if p["kind"] == "controlnet" else ("ad", tuple(tuple(v.shape) for v in p["state"])) for p in control)
+            key = (n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
+                   if hasattr(weight_func, "__code__") else id(weight_func), None) + (() if ckey is None else (ckey,))
+            st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs,
+                                   control=control)
+            scratch = torch.zeros_like(latents, dtype=text.dtype)
+
+            def set_control(s):
+                for part in control or []:
+                    v = part["schedule"](s)
+                    if part["kind"] == "controlnet":
+                        for buf, val in zip(st["cn"]["scale"], v if isinstance(v, list) else [v]):
+                            buf.fill_(float(val))
+                    else:
+                        st["ad"]["gate"].fill_(1.0 if v else 0.0)
+
+            def model_fn(x, sigma):
+                if start_time > 0 and timeout > 0:
+                    assert (time.time() - start_time) < timeout, "inference process timed out"
+                if input_hook is not None:
+                    x = input_hook(x, sigma, calls[0])
+                calls[0] += 1
+                s = float(sigma[0])                              # the host needs sigma for (c_in, t): one sync per model call
+                c_in, _, t = kdm.step_scalars(s)
+                d = x.to(text.dtype).contiguous().clone()
+                ops.prepare_unet_input(d, c_in, t, s, st["x_in"], st["t"], st["sigma"])
+                set_control(s)
+                st["run"]()
+                # a = 0, b = 1, c = 0: d <- D = x - sigma (eps_u + g (eps_c - eps_u)); the "next input" it also writes is unused
+                ops.cfg_dpmpp2m_step(d, st["eps"], scratch, s, guidance_scale, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0,
+                                     st["x_in"], st["t"], st["sigma"])
+                return d.to(x.dtype)
+
+            extra = sampler_args if sampler_args is not None else \
+                self.get_sampler_extra_args_t2i(sigmas, eta, steps, sampler_opt, latents, seed, sampler)
+            return sampler(model_fn, latents, **extra)
 
         def model_fn(x, sigma):
             if start_time > 0 and timeout > 0:
@@ -845,7 +902,35 @@ class StableDiffusionPipeline:
         return sampler(model_fn, latents, **extra)
 
     # ---- fused mode
-    def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs):
+    def _control_buffers(self, control, st=None):
+        """Static buffers of the ControlNet / T2I-Adapter parts of a captured step (control = the hooks' static
+        descriptions): conditioning embeddings computed ONCE per generation, per-call scales / gates as 0-dim device tensors
+        the model call fills before each replay.  With `st` given the existing buffers are refreshed in place."""
+        from .controlnet import MultiControlNetModel
+        out = {"cn": None, "ad": None} if st is None else st
+        for part in control or []:
+            if part["kind"] == "controlnet":
+                multi = isinstance(self.controlnet, MultiControlNetModel)
+                nets = list(self.controlnet.nets) if multi else [self.controlnet]
+                imgs = part["image"] if multi else [part["image"]]
+                embs = [n.conditioning_embedding(im) for n, im in zip(nets, imgs)]
+                if st is None:
+                    dev, dt = embs[0].device, embs[0].dtype
+                    out["cn"] = {"emb": [e.clone() for e in embs], "img": [im.clone() for im in imgs], "multi": multi,
+                                 "scale": [torch.zeros((), device=dev, dtype=dt) for _ in nets]}
+                else:
+                    for dst, src in zip(st["cn"]["emb"], embs):
+                        dst.copy_(src)
+            else:
+                if st is None:
+                    out["ad"] = {"state": [v.clone() for v in part["state"]],
+                                 "gate": torch.zeros((), device=part["state"][0].device, dtype=part["state"][0].dtype)}
+                else:
+                    for dst, src in zip(st["ad"]["state"], part["state"]):
+                        dst.copy_(src)
+        return out
+
+    def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs, control=None):
         """Static buffers + the captured UNet step.  The graph is keyed by SHAPES only: a new generation with other
         text / other region masks updates the static buffers in place (text, its packed K/V, the compressed region
         tables) and replays the same graph."""
@@ -859,6 +944,7 @@ class StableDiffusionPipeline:
             st["text"].copy_(text)
             self._refresh_text_kv(st["text"])
             self._upload_tables(st, comp_cpu, region_state)
+            self._control_buffers(control, st)
             return st
         dev, dt = text.device, text.dtype
         rows = 2 * n_img
@@ -872,6 +958,7 @@ class StableDiffusionPipeline:
         }
         if comp_cpu is not None:
             st["compressed"] = {L: (ids.to(dev), rws.to(dev)) for L, (ids, rws) in comp_cpu.items()}
+        st.update(self._control_buffers(control))
         self._refresh_text_kv(st["text"])
         kw = dict(cross_attention_kwargs)
         kw["region_prompt"] = {"region_state": region_state, "compressed": st["compressed"], "sigma": st["sigma"],
@@ -880,7 +967,18 @@ class StableDiffusionPipeline:
         ukw = {} if ack is None else {"added_cond_kwargs": {"image_embeds": st["image_embeds"]}}
 
         def step():
-            return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw, **ukw).sample
+            extra = dict(ukw)
+            if st["cn"] is not None:                # ControlNet on the same scaled input and timestep as the UNet (:1134-1142)
+                cn = st["cn"]
+                one = not cn["multi"]
+                down, mid = self.controlnet(st["x_in"], st["t"], encoder_hidden_states=st["text"],
+                                            controlnet_cond=cn["img"][0] if one else cn["img"],
+                                            conditioning_scale=cn["scale"][0] if one else cn["scale"], guess_mode=False,
+                                            return_dict=False, cond_embedding=cn["emb"][0] if one else cn["emb"])
+                extra.update({"down_block_additional_residuals": down, "mid_block_additional_residual": mid})
+            if st["ad"] is not None:                # T2I-Adapter features, gated per call (0 = the reference passes none)
+                extra["down_intrablock_additional_residuals"] = [v * st["ad"]["gate"] for v in st["ad"]["state"]]
+            return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw, **extra).sample
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))

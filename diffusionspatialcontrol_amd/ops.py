@@ -517,6 +517,7 @@ def geglu(x):
 
 # ----------------------------------------------------------------------------- sampler step
 GRAPHS_ENABLED = True      # the fused pipeline captures the UNet step into a HIP graph (torch.cuda.CUDAGraph)
+PROTOCOL_GRAPH = os.environ.get("DSC_PROTOCOL_GRAPH", "1") != "0"   # protocol-mode model calls replay the same graph
 
 
 def prepare_unet_input(x, c_in, t, sigma, x_in, t_buf, sigma_buf):
