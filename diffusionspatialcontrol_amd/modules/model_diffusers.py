@@ -157,6 +157,13 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
         on the scaled input, ONE UNet call, `u + g (c - u)`, optional rescale, scheduler.step, optional post-step hook
         (inpainting's re-imposition of the known region)."""
         cfg = self.do_classifier_free_guidance
+        from .. import ops
+        n_img = latents.shape[0]
+        if (ops.PROTOCOL_GRAPH and cfg and fixed_residuals is None and added_cond_kwargs is None and latents.is_cuda
+                and text.dtype == torch.float16 and (control is None or not control["guess_mode"])
+                and latents.numel() // n_img % 8 == 0):
+            return self._denoise_graph(latents, ts, text, region_state, weight_func, guidance_scale, guidance_rescale,
+                                       ca_kwargs, callback_on_step_end, control, after_step)
         self._text_kv_for(text)
         for i, t in enumerate(ts):
             x_in = torch.cat([latents] * 2) if cfg else latents                                       # :345
@@ -197,6 +204,47 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
         change between steps); the k-diffusion pipeline's helper works on its static buffers, here on the plain tensor"""
         self._refresh_text_kv(text)
 
+
+    def _denoise_graph(self, latents, ts, text, region_state, weight_func, guidance_scale, guidance_rescale, ca_kwargs,
+                       callback_on_step_end, control, after_step):
+        """The same loop with the UNet (+ ControlNet) call replayed from the k-diffusion pipeline's captured step graph: static
+        input / timestep / sigma buffers are filled per step (`sigma = scheduler.sigmas[i]`, whole-batch std: n_std_groups = 1);
+        CFG combine and `scheduler.step` stay the scheduler object's eager arithmetic."""
+        n_img = latents.shape[0]
+        static_control = None
+        if control is not None:
+            static_control = [{"kind": "controlnet", "image": control["image"]}]
+        levels = tuple(sorted((int(L), tuple(w.shape)) for L, w in region_state.items())) if isinstance(region_state, dict) else None
+        ckey = None if control is None else (("cn", id(self.controlnet), tuple(
+            tuple(i.shape) for i in (control["image"] if isinstance(control["image"], list) else [control["image"]]))),)
+        key = ("diffusers", n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype,
+               id(weight_func.__code__) if hasattr(weight_func, "__code__") else id(weight_func), ckey)
+        st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, ca_kwargs,
+                               control=static_control, n_std_groups=1)
+        for i, t in enumerate(ts):
+            x_in = self.scheduler.scale_model_input(torch.cat([latents] * 2), t)                      # :345-346
+            st["x_in"].copy_(x_in.to(text.dtype))
+            st["t"].fill_(float(t))
+            st["sigma"].fill_(float(self.scheduler.sigmas[i]))                                        # :349-354, loop index (q5)
+            if control is not None:
+                keep = control["keep"][i]
+                sc_ = control["scale"]
+                vals = [c_ * s_ for c_, s_ in zip(sc_, keep)] if isinstance(keep, list) else \
+                    [(sc_[0] if isinstance(sc_, list) else sc_) * keep]
+                for buf, v in zip(st["cn"]["scale"], vals):
+                    buf.fill_(float(v))
+            st["run"]()
+            u, c = st["eps"].chunk(2)
+            eps = u + guidance_scale * (c - u)                                                        # :381-383
+            if guidance_rescale > 0.0:
+                eps = rescale_noise_cfg(eps, c, guidance_rescale=guidance_rescale)                    # :385-387
+            latents = self.scheduler.step(eps, t, latents, return_dict=False)[0]                      # :390
+            if after_step is not None:
+                latents = after_step(i, t, latents)
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": latents})
+                latents = out.pop("latents", latents)
+        return latents
 
     # ---- pieces shared by the other five classes
     def _prepare_call(self, prompt, negative_prompt, prompt_embeds, negative_prompt_embeds, text_input_ids, guidance_scale,

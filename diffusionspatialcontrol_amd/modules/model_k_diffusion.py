@@ -930,7 +930,8 @@ class StableDiffusionPipeline:
                         dst.copy_(src)
         return out
 
-    def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs, control=None):
+    def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs, control=None,
+                     n_std_groups=None):
         """Static buffers + the captured UNet step.  The graph is keyed by SHAPES only: a new generation with other
         text / other region masks updates the static buffers in place (text, its packed K/V, the compressed region
         tables) and replays the same graph."""
@@ -962,7 +963,7 @@ class StableDiffusionPipeline:
         self._refresh_text_kv(st["text"])
         kw = dict(cross_attention_kwargs)
         kw["region_prompt"] = {"region_state": region_state, "compressed": st["compressed"], "sigma": st["sigma"],
-                               "weight_func": weight_func, "n_std_groups": n_img}
+                               "weight_func": weight_func, "n_std_groups": n_img if n_std_groups is None else n_std_groups}
 
         ukw = {} if ack is None else {"added_cond_kwargs": {"image_embeds": st["image_embeds"]}}
 
