@@ -359,7 +359,8 @@ class StableDiffusionInpaintPipeline_finetune(StableDiffusionPipeline_finetune):
             raise NotImplementedError("raw IP-Adapter images, T2I-Adapter, latent previews, custom timestep lists and mask "
                                       "cropping are 'next' rows (SURVEY.md 8f)")
         if self.unet.config.in_channels != 4:
-            raise NotImplementedError("the 9-channel inpainting UNet is a 'next' row (conv_in kernel: <= 8 input channels)")
+            raise NotImplementedError("the 9-channel inpainting UNet is served by the k-diffusion pipeline's `inpaiting`; this "
+                                      "diffusers-scheduler class implements the 4-channel branch")
         if image is None or mask_image is None:
             raise ValueError("inpainting needs `image` and `mask_image`")
         height = height or self.unet.config.sample_size * self.vae_scale_factor

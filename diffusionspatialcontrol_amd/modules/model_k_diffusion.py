@@ -746,15 +746,15 @@ class StableDiffusionPipeline:
                   ip_adapter_image_embeds=None,
                   prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                   text_input_ids=None, **unsupported):
-        """reference :1365-1760 (method name as spelled there), the 4-channel UNet branch: the known region
-        `image_latents + sigma * noise` is re-imposed on the model input before every model call after the first
-        (:1599-1612).  Protocol mode only (the blend is a hook on the model input)."""
+        """reference :1365-1760 (method name as spelled there).  4-channel UNet: the known region `image_latents + sigma * noise` is
+        re-imposed on the model input before every model call after the first (:1599-1612).  9-channel UNet (the inpainting
+        checkpoints): mask and masked-image latents are concatenated to the duplicated latent (:1617-1619) - eager protocol mode."""
         if upscale or latent_processing or padding_mask_crop is not None:
             raise NotImplementedError("hires upscale / latent previews / mask cropping are outside the denoising hot path "
                                       "built here")
-        if self.unet.config.in_channels != 4:
-            raise NotImplementedError("the 9-channel inpainting UNet (mask + masked-image latents concatenated to the "
-                                      "input) is a 'next' row: the few-channel conv_in kernel takes <= 8 input channels")
+        num_channels_unet = self.unet.config.in_channels
+        if num_channels_unet not in (4, 9):
+            raise ValueError(f"The unet {self.unet.__class__} should have either 4 or 9 input channels, not {num_channels_unet}.")
         if image is None or mask_image is None:
             raise ValueError("inpaiting needs `image` and `mask_image`")
         sampler = self.get_scheduler(sampler_name) if isinstance(sampler_name, str) else sampler_name
@@ -774,10 +774,23 @@ class StableDiffusionPipeline:
             n_img, 4, height, width, text.dtype, device, generator, latents, image=init_image, sigma=sigmas[0],
             is_strength_max=is_strength_max, return_noise=True, return_image_latents=True)           # :1459-1478
         mask = self._image_tensor(mask_image, height, width, mask=True)
+        extra_input = None
+        if num_channels_unet == 9:                               # :1253-1290, :1617-1619: [latents | mask | masked-image latents]
+            if masked_image_latents is None:
+                if init_image.shape[1] == 4:
+                    raise ValueError("the 9-channel UNet needs pixels (or masked_image_latents) to build the masked image")
+                masked = init_image * (mask < 0.5)
+                masked_image_latents = self._encode_vae_image(masked, generator)
+            mil = masked_image_latents.to(device=device, dtype=text.dtype)
+            if mil.shape[0] < n_img:
+                mil = mil.repeat(n_img // mil.shape[0], 1, 1, 1)
         mask = torch.nn.functional.interpolate(mask, size=(height // self.vae_scale_factor, width // self.vae_scale_factor))
         mask = mask.to(device=device, dtype=text.dtype)                                              # :1253-1257
         if mask.shape[0] < n_img:
             mask = mask.repeat(n_img // mask.shape[0], 1, 1, 1)
+        if num_channels_unet == 9:
+            rows = 2 if self.do_classifier_free_guidance else 1
+            extra_input = torch.cat([torch.cat([mask] * rows), torch.cat([mil] * rows)], dim=1)
         region_state = encode_region_map(self, region_map_state, width=width, height=height,
                                          num_images_per_prompt=num_images_per_prompt, text_ids=text_input_ids)
         cross_attention_kwargs = {} if cross_attention_kwargs is None else cross_attention_kwargs
@@ -789,7 +802,7 @@ class StableDiffusionPipeline:
         sig_last = float(sigmas[-1])
 
         def keep_known_region(x, sigma, call_index):                                                 # :1599-1612
-            if call_index == 0:
+            if call_index == 0 or num_channels_unet != 4:
                 return x
             s = float(sigma[0])
             known = image_latents
@@ -808,16 +821,18 @@ class StableDiffusionPipeline:
         latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                          guidance_rescale, n_img, cross_attention_kwargs, eta, num_inference_steps,
                                          sampler_opt, seed, start_time, timeout, input_hook=keep_known_region,
-                                         control_hook=control_hook)
+                                         control_hook=control_hook, extra_input=extra_input)
         return [self.latent_to_image(latents, output_type)]
 
     # ---- protocol mode: the reference's model_fn closure (:1091-1171) + sampler call (:1172-1175)
     def _denoise_protocol(self, sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                           guidance_rescale, n_img, cross_attention_kwargs, eta, steps, sampler_opt, seed, start_time,
-                          timeout, sampler_args=None, input_hook=None, control_hook=None):
+                          timeout, sampler_args=None, input_hook=None, control_hook=None, extra_input=None):
         """sampler_args: the keyword arguments for `sampler` when the caller built them itself (img2img's
         get_sampler_extra_args_i2i); input_hook(x, sigma, call_index) -> x: applied to the model input (inpainting's
-        re-imposition of the known region, reference :1599-1612)"""
+        re-imposition of the known region, reference :1599-1612); extra_input [rows, c, h, w]: channels concatenated to the
+        duplicated latent before the denoiser (the 9-channel inpainting UNet's mask + masked-image latents, :1617-1619 - the
+        denoiser's c_in then scales them too, as in the reference)"""
         cfg = self.do_classifier_free_guidance
         kdm = self.k_diffusion_model
         calls = [0]
@@ -827,7 +842,7 @@ class StableDiffusionPipeline:
         # Every sampler then runs at graph speed; only its own update arithmetic stays eager.
         control = None if control_hook is None else getattr(control_hook, "static", None)
         use_graph = (ops.PROTOCOL_GRAPH and (control_hook is None or control is not None) and cfg and guidance_rescale == 0.0
-                     and not self.v_prediction and latents.is_cuda and text.dtype == torch.float16
+                     and not self.v_prediction and latents.is_cuda and text.dtype == torch.float16 and extra_input is None
                      and self._added_cond_kwargs is None and latents.numel() // latents.shape[0] % 8 == 0)
         if use_graph:
             levels = tuple(sorted((int(L), tuple(w.shape)) for L, w in region_state.items())) \
@@ -878,6 +893,8 @@ class StableDiffusionPipeline:
                 x = input_hook(x, sigma, calls[0])
             calls[0] += 1
             latent_model_input = torch.cat([x] * 2) if cfg else x
+            if extra_input is not None:
+                latent_model_input = torch.cat([latent_model_input, extra_input.to(latent_model_input.dtype)], dim=1)
             cross_attention_kwargs["region_prompt"] = {
                 "region_state": region_state, "sigma": sigma[0], "weight_func": weight_func, "n_std_groups": n_img}
             if latent_model_input.dtype != text.dtype:

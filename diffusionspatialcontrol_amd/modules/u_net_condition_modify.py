@@ -540,7 +540,7 @@ class _EncoderHalf:
 
     def _conv_in(self, sample):
         ci = self.conv_in
-        if (sample.is_cuda and sample.dtype == torch.float16 and ci.in_channels <= 8 and ci.out_channels % 8 == 0
+        if (sample.is_cuda and sample.dtype == torch.float16 and ci.in_channels <= 16 and ci.out_channels % 8 == 0
                 and ci.out_channels <= 512 and sample.shape[-1] % 8 == 0 and ops.USE_DSC_CONV):
             wt = _derived(self, "conv_in_t", (ci.weight,), lambda: ci.weight.reshape(ci.out_channels, -1).t().contiguous())
             return ops.conv3x3_fewcin(sample, wt, ci.bias, ci.out_channels)   # NCHW latents -> NHWC features, one launch

@@ -229,7 +229,7 @@ class AutoencoderKL(AutoencoderKLDecoder):
         cl = torch.channels_last
         x = x.to(self.dtype)
         wt = _derived_w(e.conv_in, "fewcin", lambda w: w.reshape(w.shape[0], -1).t().contiguous())
-        if x.is_cuda and x.dtype == torch.float16 and x.shape[1] <= 8:
+        if x.is_cuda and x.dtype == torch.float16 and x.shape[1] <= 16:
             h = ops.conv3x3_fewcin(x, wt, e.conv_in.bias, e.conv_in.out_channels)          # NCHW image in, channels-last out
         else:
             h = e.conv_in(x).contiguous(memory_format=cl)

@@ -434,7 +434,7 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_n
 
 
 def conv3x3_fewcin(x, weight_t, bias, cout):
-    """3x3 / pad 1 convolution of a plain (NCHW) fp16 [B, Cin <= 8, H, W] tensor -> channels_last [B, cout, H, W]
+    """3x3 / pad 1 convolution of a plain (NCHW) fp16 [B, Cin <= 16, H, W] tensor -> channels_last [B, cout, H, W]
     (dsc_conv3x3_fewcin_f16); weight_t is weight.reshape(cout, Cin * 9).t().contiguous()."""
     _require_gpu(x, weight_t)
     x = x.contiguous()

@@ -265,7 +265,7 @@ int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void
                       int dtype, void* stream);
 
 /*
- * 3x3 / pad 1 convolution with few input channels (<= 8) - the UNet's `conv_in` (4 -> 320; reference
+ * 3x3 / pad 1 convolution with few input channels (<= 16) - the UNet's `conv_in` (4 -> 320; reference
  * u_net_condition_modify.py:352-356,1187): x [B,Cin,H,W] channel-major fp16 (the sampler's latent layout),
  * w_t [9*Cin, Cout] = weight.reshape(Cout, Cin*9).t() (k = (ci*3 + dy)*3 + dx), out [B,H,W,Cout] channels-last, bias fused.
  * Cout % 8 == 0, Cout <= 512, W % 8 == 0.

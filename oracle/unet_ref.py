@@ -192,7 +192,8 @@ def unet_forward(sd, cfg, sample, timestep, enc, region_prompt=None, n_std_group
 
 
 def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, steps_limit=None, on_step=None,
-                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False, controlnet=None, adapter=None):
+                 sampler=None, sampler_kwargs=None, input_hook=None, v_prediction=False, controlnet=None, adapter=None,
+                 extra_input=None):
     """txt2img's loop for n_img images in the row layout [u_0.., c_0..]; returns the final latents (fp32).
 
     latents: initial noise ALREADY multiplied by sqrt(sigma_0^2 + 1) (model_k_diffusion.py:1043);
@@ -214,6 +215,8 @@ def denoise_loop(sd, cfg, latents, sigmas, text, region_state, guidance_scale, s
             x = input_hook(x, sigma, calls[0])
         calls[0] += 1
         inp = torch.cat([x] * 2)                                                      # :1097
+        if extra_input is not None:                    # 9-channel inpainting UNet: [latents | mask | masked-image latents] (:1617)
+            inp = torch.cat([inp, extra_input.float()], dim=1)
         rp = {"region_state": region_state, "sigma": float(sigma[0]), "weight_func": ra.default_weight_func}
 
         def eps_fn(xin, t, **kw):

@@ -988,6 +988,48 @@ def test_t2i_adapter_pipeline_vs_oracle(ops):
         pipe.txt2img(None, height=128, width=128, image_t2i_adapter=img, **kw)
 
 
+def test_inpainting_9_channel_unet(ops):
+    """The inpainting checkpoints' UNet takes 9 input channels: [latents | mask | masked-image latents] (reference
+    model_k_diffusion.py:1617-1619; the denoiser's c_in scales all nine, as the reference's call order makes it).  conv_in runs
+    on the few-channel kernel (<= 16 channels).  Product vs the oracle loop with the same extra channels."""
+    from diffusionspatialcontrol_amd.modules import sampling
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
+    import dataclasses
+    torch.manual_seed(4)
+    cfg = dataclasses.replace(UNetConfig.tiny(), in_channels=9)
+    unet = UNet2DConditionModel(cfg).half()
+    sd = {k: v.clone() for k, v in unet.state_dict().items()}
+    unet = unet.cuda()
+    g = torch.Generator().manual_seed(7)
+    text = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).half()
+    state, ids, rs = _region_state(n_img=1)
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    img_lat = (torch.randn(1, 4, 16, 16, generator=g) * 0.7).half()
+    mil = (torch.randn(1, 4, 16, 16, generator=g) * 0.7).half()
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[..., 32:96] = 1.0
+    steps = 4
+    out = pipe.inpaiting(None, image=img_lat.clone(), mask_image=mask, masked_image_latents=mil.clone(), height=128, width=128,
+                         num_inference_steps=steps, guidance_scale=7.5, output_type="latent", region_map_state=state,
+                         sampler_name="sample_euler", sampler_opt={"scheduler": "karras"}, prompt_embeds=text[1:2],
+                         negative_prompt_embeds=text[:1], text_input_ids=ids,
+                         generator=torch.Generator().manual_seed(3))[0].float().cpu()
+    sig = pipe.get_sigmas(steps, {"scheduler": "karras"}).half().float().cpu()
+    noise = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(3), dtype=torch.float16).float()
+    m16 = F.interpolate(mask, size=(16, 16))
+    extra = torch.cat([torch.cat([m16] * 2), torch.cat([mil.float()] * 2)], dim=1)
+    ref = unet_ref.denoise_loop(sd, cfg, noise * math.sqrt(float(sig[0]) ** 2 + 1), sig.tolist(), text.float(), rs, 7.5,
+                                sampler=sampling.sample_euler, extra_input=extra)
+    sc = ref.abs().max().item()
+    assert out.shape == (1, 4, 16, 16) and torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() < 4e-2 * sc, ((out - ref).abs().max().item(), sc)
+    with pytest.raises(ValueError):
+        pipe.inpaiting(None, image=img_lat.clone(), mask_image=mask, height=128, width=128, num_inference_steps=2,
+                       prompt_embeds=text[1:2], negative_prompt_embeds=text[:1], output_type="latent",
+                       sampler_name="sample_euler")                                    # no pixels, no masked latents
+
+
 def test_ip_adapter_unet_and_pipeline(ops):
     """IP-Adapter weights load into the UNet with the published key numbering (cross-attention
     layers numbered 1, 3, 5, ... over down_blocks, up_blocks, mid_block), the image tokens reach every cross-attention
