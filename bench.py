@@ -21,6 +21,7 @@ Extra objects on the JSON line:
   roofline_self_attn - the flash self-attention kernel at the same level against the 2.5 PFLOP/s dense fp16 MFMA peak
                  (4*L^2*C FLOPs per row).
   roofline_conv3x3   - the 3x3 convolution kernel (64x64, 320->320, the most frequent one) against the same peak
+  roofline_at_8_images - the same three kernels at Bc = 16 (BASELINE configs[2]: 8 images per GPU): achieved / frac / launch time
   cpu_baseline - the oracle (oracle/unet_ref.py, torch fp32, op-for-op unfused like the reference) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -319,6 +320,13 @@ def main():
         res["roofline"] = roofline_region_xattn(dev, n_img)
         res["roofline_self_attn"] = roofline_self_attn(dev, n_img)
         res["roofline_conv3x3"] = roofline_conv3x3(dev, n_img)
+        if n_img == 1:
+            # the same three kernels at the batch of BASELINE configs[2] (8 images per GPU, Bc = 16): what they reach once a
+            # launch has enough workgroups to fill the chip - the bench workload above (Bc = 2) is launch-latency bound
+            pick = lambda r: {k_: r[k_] for k_ in ("achieved", "unit", "frac", "avg_launch_us")}    # noqa: E731
+            res["roofline_at_8_images"] = {"region_xattn": pick(roofline_region_xattn(dev, 8)),
+                                           "self_attn": pick(roofline_self_attn(dev, 8)),
+                                           "conv3x3": pick(roofline_conv3x3(dev, 8))}
         if world == 1 and not a.no_cpu_baseline:
             from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
             rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)
