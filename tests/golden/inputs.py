@@ -263,3 +263,63 @@ def sampler_start(n_sigmas):
     sigmas = torch.cat([(hi + ramp * (lo - hi)) ** 7.0, torch.zeros(1, dtype=torch.float64)])
     x = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64) * sigmas[0]
     return x, sigmas
+
+
+# ----------------------------------------------------------------------------- long_encode 1 / 2 (tests/golden/prompt_encoders.npz)
+class FakeHFClipTokenizer(FakeClipTokenizer):
+    """FakeClipTokenizer with the transformers call surface reference encoder_prompt_modify.py uses for `long_encode` 1 / 2
+    (:127-160, :540-560, :640-650): special tokens added, `padding` ("max_length" / "longest"), `truncation`, `return_tensors`,
+    list input, `batch_decode`, `pad_token_id`."""
+    pad_token_id = 49407
+
+    def _one(self, text, max_length, truncation):
+        ids = [self.bos_token_id] + self._ids(text) + [self.eos_token_id]
+        if truncation and max_length is not None and len(ids) > max_length:
+            ids = ids[:max_length - 1] + [self.eos_token_id]
+        return ids
+
+    def __call__(self, text, padding=False, max_length=None, truncation=False, return_tensors=None, **kw):
+        import torch
+        single = not isinstance(text, (list, tuple))
+        rows = [self._one(t, max_length, truncation) for t in ([text] if single else text)]
+        if padding == "max_length":
+            rows = [r + [self.pad_token_id] * (max_length - len(r)) for r in rows]
+        elif padding == "longest":
+            n = max(len(r) for r in rows)
+            rows = [r + [self.pad_token_id] * (n - len(r)) for r in rows]
+        mask = [[1] * len(r) for r in rows]
+        if return_tensors == "pt":
+            return type("Enc", (), {"input_ids": torch.tensor(rows, dtype=torch.long), "attention_mask": torch.tensor(mask)})()
+        return type("Enc", (), {"input_ids": rows[0] if single else rows, "attention_mask": mask[0] if single else mask})()
+
+    def batch_decode(self, ids):
+        return [" ".join(str(int(v)) for v in row) for row in ids]
+
+
+def fake_hf_text_encoder(dim=32, layers=3, seed=11):
+    """fake_text_encoder with the transformers return convention those branches index: out[0] = last hidden state (final
+    LayerNorm applied), out[-1] = the tuple of hidden states when output_hidden_states=True; `attention_mask` accepted."""
+    import torch
+    base = fake_text_encoder(dim, layers, seed)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.text_model = base.text_model
+            self.config = type("Cfg", (), {})()
+            self.device, self.dtype = torch.device("cpu"), torch.float32
+
+        def forward(self, tokens, attention_mask=None, output_hidden_states=False):
+            o = base(tokens, output_hidden_states=True)
+            pooled = o.last_hidden_state[:, -1]
+            return (o.last_hidden_state, pooled, o.hidden_states) if output_hidden_states else (o.last_hidden_state, pooled)
+
+    return Enc()
+
+
+def prompt_encoder_cases():
+    """(negative, prompt) pairs for the lpw-style (`long_encode=1`) and plain (`long_encode=2`) encoders"""
+    long_a = ", ".join(f"item{i} with detail" for i in range(30))                 # ~150 tokens: three chunks after weighting
+    return [("blurry, low quality", "a (red:1.3) apple on a [wooden] table"), ("", long_a),
+            ("(worst quality:1.4), lowres", "((masterpiece)), (" + long_a + ":0.9), [background]"),
+            ("text, watermark", "plain prompt without weights")]

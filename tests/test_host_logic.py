@@ -514,3 +514,28 @@ def test_ip_adapter_raw_image_encoding():
     pipe.image_encoder = None
     with pytest.raises(NotImplementedError):
         pipe.encode_image(img, "cpu", 1)
+
+
+def test_long_encode_branches_match_reference_goldens():
+    """`encode_prompt_function(long_encode=1 / 2)` (reference encoder_prompt_modify.py:395-490 "long prompt weighting",
+    :492-689 plain 77-token CLIP) against outputs of the REFERENCE's own functions on the deterministic fake tokenizer /
+    encoder (tests/golden/make_golden_prompts.py): embeddings and token ids, with and without clip skip"""
+    from inputs import FakeHFClipTokenizer, fake_hf_text_encoder, prompt_encoder_cases
+    from diffusionspatialcontrol_amd.modules import encoder_prompt_modify as ep
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "prompt_encoders.npz"))
+    pipe = types.SimpleNamespace(tokenizer=FakeHFClipTokenizer(), text_encoder=fake_hf_text_encoder(),
+                                 device=torch.device("cpu"), unet=None)
+    with torch.no_grad():
+        for i, (neg, pos) in enumerate(prompt_encoder_cases()):
+            for cs in (None, 2):
+                for kind, le in (("long", 1), ("short", 2)):
+                    pe, ne, ids = ep.encode_prompt_function(pipe, pos, "cpu", 2, True, neg, clip_skip=cs, long_encode=le)
+                    tag = f"{kind}/{i}/skip{cs or 0}"
+                    assert np.abs(pe.numpy() - g[tag + "/pos"]).max() < 1e-6 and np.abs(ne.numpy() - g[tag + "/neg"]).max() < 1e-6, tag
+                    assert np.array_equal(ids[0], g[tag + "/neg_ids"]) and np.array_equal(ids[1], g[tag + "/pos_ids"]), tag
+        pe, ne, ids = ep.encoder_long_prompt(pipe, prompt_encoder_cases()[0][1], "cpu", 1, False)
+        assert ne is None and ids[0] is None and np.abs(pe.numpy() - g["long/nocfg/pos"]).max() < 1e-6
+    assert ep.parse_prompt_attention("a (((house:1.3)) [on] a (hill:0.5), sun, (((sky))).")[1] == ["house", 1.5730000000000004]
+    assert ep.parse_prompt_attention("one BREAK two") == [["one BREAK two", 1.0]]          # no BREAK keyword in this variant
+    with pytest.raises(ValueError):
+        ep.encoder_long_prompt(pipe, ["a", "b"], "cpu", 1, True, ["only one"])
