@@ -2,15 +2,20 @@
 `source/modules/model_k_diffusion.py` (`ModelWrapper` :85-98, `StableDiffusionPipeline` :101-, `setup_unet`
 :138-141, `get_scheduler` :143-146, `get_sigmas` :848-882, `prepare_latents` :428-456, `txt2img` :943-1231).
 
-Scope: the denoising loop of `txt2img`.  Prompt encoding (CLIP + A1111 chunking),
-VAE decode, ControlNet / T2I-Adapter / IP-Adapter and hires-upscale are the "next" rows and raise
-NotImplementedError when requested; embeddings and token ids are passed in (`prompt_embeds`,
-`negative_prompt_embeds`, `text_input_ids`), and `output_type="latent"` returns the final latents.
+Scope (SURVEY.md 8a rows a6-a10, 8f and the callers around them): `txt2img` (:943-1231), `img2img` (:543-846), `inpaiting`
+(:1365-1760; 4- and 9-channel UNets), hires upscale, ControlNet (`setup_controlnet` / `preprocess_controlnet`, :348-427),
+T2I-Adapter, IP-Adapter (embeddings or raw images through `encode_image`), prompt strings through
+`encoder_prompt_modify.encode_prompt_function` (all three `long_encode` branches), every sampler `app.py:170-220` lists, eps-
+and v-prediction.  Not built (NotImplementedError): latent previews (`latent_processing`), mask cropping, LoRA scaling of the
+text encoder, textual inversion.  `output_type="latent"` (an extra of this build) returns the final latents.
 
 Two execution modes produce the same numbers:
-  * protocol mode (`fused=False`): the reference's control flow - a `model_fn(x, sigma)` closure that duplicates the
-    latent, attaches `region_prompt`, calls `CompVisDenoiser` -> `ModelWrapper.apply_model` -> UNet, combines CFG
-    (:1091-1171) - handed to `sampler(model_fn, latents, sigmas=...)` (:1175).  Any sampler callable works.
+  * protocol mode (`fused=False`): the reference's control flow - a `model_fn(x, sigma)` closure handed to
+    `sampler(model_fn, latents, sigmas=...)` (:1175), any sampler callable.  The closure's body is graph-backed where nothing
+    but (x, sigma) changes per call: one launch writes the static inputs, ONE replay of the captured UNet (+ ControlNet /
+    adapter) step, one launch does CFG + eps -> denoised; otherwise (v-prediction, IP-Adapter embeddings, CFG rescale, 9-channel
+    inpainting) it is the reference's eager sequence - duplicate the latent, attach `region_prompt`, `CompVisDenoiser` ->
+    `ModelWrapper.apply_model` -> UNet, combine CFG (:1091-1171).
   * fused mode (`fused=True`, default for `sample_dpmpp_2m`): the UNet forward of one step is captured ONCE into a
     HIP graph over static buffers (sigma and the timestep are device scalars, so the same graph serves all 25
     steps); between replays ONE HIP launch (dsc_cfg_dpmpp2m_step) does CFG combine + eps->denoised + the DPM++ 2M
