@@ -6,8 +6,8 @@ Scope (SURVEY.md 8a rows a6-a10, 8f and the callers around them): `txt2img` (:94
 (:1365-1760; 4- and 9-channel UNets), hires upscale, ControlNet (`setup_controlnet` / `preprocess_controlnet`, :348-427),
 T2I-Adapter, IP-Adapter (embeddings or raw images through `encode_image`), prompt strings through
 `encoder_prompt_modify.encode_prompt_function` (all three `long_encode` branches), every sampler `app.py:170-220` lists, eps-
-and v-prediction.  Not built (NotImplementedError): latent previews (`latent_processing`), mask cropping, LoRA scaling of the
-text encoder, textual inversion.  `output_type="latent"` (an extra of this build) returns the final latents.
+and v-prediction.  Latent previews (`latent_processing == 1`) return the list of per-model-call estimates as the reference does.
+Not built (NotImplementedError): mask cropping, LoRA scaling of the text encoder, textual inversion.  `output_type="latent"` (an extra of this build) returns the final latents.
 
 Two execution modes produce the same numbers:
   * protocol mode (`fused=False`): the reference's control flow - a `model_fn(x, sigma)` closure handed to
@@ -426,12 +426,11 @@ class StableDiffusionPipeline:
                 # build-specific inputs (the prompt encoders are a "next" row):
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
                 text_input_ids=None, fused: Optional[bool] = None, **unsupported):
-        if latent_processing:
-            raise NotImplementedError("latent previews are outside the denoising hot path built here (SURVEY.md 8f)")
         hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                      negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
                      sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
                      region_map_state=region_map_state, seed=seed, control_img=control_img,
+                     latent_processing=unsupported.get("latent_upscale_processing", False),
                      controlnet_conditioning_scale=controlnet_conditioning_scale, control_guidance_start=control_guidance_start,
                      control_guidance_end=control_guidance_end, image_t2i_adapter=image_t2i_adapter,
                      adapter_conditioning_scale=adapter_conditioning_scale, adapter_conditioning_factor=adapter_conditioning_factor,
@@ -485,21 +484,28 @@ class StableDiffusionPipeline:
         control_hook = self._merge_hooks(control_hook, self._adapter_hook(
             image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height, len(sigmas),
             num_images_per_prompt))                                                                         # :1086-1089
+        preview = None
+        if latent_processing == 1:                               # :1083-1084: previews of every model call's estimate
+            latents_process = [self.latent_to_image(latents, output_type)]
+            preview = (latents_process, output_type)
         if fused is None:
             fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and cfg and not self.v_prediction \
-                and control_hook is None
+                and control_hook is None and preview is None
         if fused:
-            if control_hook is not None:
-                raise NotImplementedError("ControlNet runs in protocol mode (fused=False): the captured step graph holds the UNet only")
+            if control_hook is not None or preview is not None:
+                raise NotImplementedError("ControlNet / T2I-Adapter / latent previews run in protocol mode (fused=False)")
             latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout)
         else:
             latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                              guidance_rescale, n_img, cross_attention_kwargs, eta,
                                              num_inference_steps, sampler_opt, seed, start_time, timeout,
-                                             control_hook=control_hook)
+                                             control_hook=control_hook, preview=preview)
         if upscale:                                                                                          # :1176-1228
-            return self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
+            res = self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
+            return latents_process + res if latent_processing == 1 else res
+        if latent_processing == 1:                               # :1229-1230 (the list ends with the last model call's estimate)
+            return latents_process
         return [self.latent_to_image(latents, output_type)]
 
     def get_sampler_extra_args_i2i(self, sigmas, steps, sampler_opt, latents, seed, func):
@@ -630,12 +636,11 @@ class StableDiffusionPipeline:
         """reference :543-846: encode the image (or take `latents`), keep the last `strength` fraction of the schedule, add
         noise, denoise.  Reproduces the reference's start: `latents + noise * sqrt(sigma_0^2 + 1)` (:647 - sic, not
         `noise * sigma_0`)."""
-        if latent_processing:
-            raise NotImplementedError("latent previews are outside the denoising hot path built here (SURVEY.md 8f)")
         hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                      negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
                      sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
                      region_map_state=region_map_state, seed=seed, control_img=control_img,
+                     latent_processing=unsupported.get("latent_upscale_processing", False),
                      controlnet_conditioning_scale=controlnet_conditioning_scale, control_guidance_start=control_guidance_start,
                      control_guidance_end=control_guidance_end, image_t2i_adapter=image_t2i_adapter,
                      adapter_conditioning_scale=adapter_conditioning_scale, adapter_conditioning_factor=adapter_conditioning_factor,
@@ -682,12 +687,16 @@ class StableDiffusionPipeline:
         control_hook = self._merge_hooks(control_hook, self._adapter_hook(
             image_t2i_adapter, adapter_conditioning_scale, adapter_conditioning_factor, width, height, len(sigma_sched),
             num_images_per_prompt))                                                                         # :700-703
+        preview = None
+        if latent_processing == 1:                               # :696-697
+            latents_process = [self.latent_to_image(latents, output_type)]
+            preview = (latents_process, output_type)
         if fused is None:
             fused = sampler is sampling.sample_dpmpp_2m and guidance_rescale == 0.0 and self.do_classifier_free_guidance \
-                and not self.v_prediction and control_hook is None
+                and not self.v_prediction and control_hook is None and preview is None
         if fused:
-            if control_hook is not None:
-                raise NotImplementedError("ControlNet runs in protocol mode (fused=False)")
+            if control_hook is not None or preview is not None:
+                raise NotImplementedError("ControlNet / T2I-Adapter / latent previews run in protocol mode (fused=False)")
             latents = self._denoise_fused(latents, sigma_sched, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout)
         else:
@@ -695,9 +704,12 @@ class StableDiffusionPipeline:
             latents = self._denoise_protocol(sampler, latents, sigma_sched, text, region_state, weight_func, guidance_scale,
                                              guidance_rescale, n_img, cross_attention_kwargs, 0.0, len(sigma_sched),
                                              sampler_opt, seed, start_time, timeout, sampler_args=args,
-                                             control_hook=control_hook)
+                                             control_hook=control_hook, preview=preview)
         if upscale:                                                                                          # :789-838
-            return self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
+            res = self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
+            return latents_process + res if latent_processing == 1 else res
+        if latent_processing == 1:                               # :841-842
+            return latents_process
         return [self.latent_to_image(latents, output_type)]
 
     def _sigma_to_alpha_sigma_t(self, sigma):
@@ -754,8 +766,8 @@ class StableDiffusionPipeline:
         """reference :1365-1760 (method name as spelled there).  4-channel UNet: the known region `image_latents + sigma * noise` is
         re-imposed on the model input before every model call after the first (:1599-1612).  9-channel UNet (the inpainting
         checkpoints): mask and masked-image latents are concatenated to the duplicated latent (:1617-1619) - eager protocol mode."""
-        if upscale or latent_processing or padding_mask_crop is not None:
-            raise NotImplementedError("hires upscale / latent previews / mask cropping are outside the denoising hot path "
+        if upscale or padding_mask_crop is not None:
+            raise NotImplementedError("hires upscale after inpainting and mask cropping are outside the denoising hot path "
                                       "built here")
         num_channels_unet = self.unet.config.in_channels
         if num_channels_unet not in (4, 9):
@@ -817,6 +829,10 @@ class StableDiffusionPipeline:
             rate = (s ** 2 + 1) ** 0.5
             return ((1 - mask) * known + mask * x / rate) * rate
 
+        preview = None
+        if latent_processing == 1:                               # :1584-1585
+            latents_process = [self.latent_to_image(latents, output_type)]
+            preview = (latents_process, output_type)
         control_hook = self._controlnet_hook(control_img, controlnet_conditioning_scale, control_guidance_start,
                                              control_guidance_end, width, height, num_inference_steps, n_img,
                                              num_images_per_prompt, text)                                    # :1577-1578
@@ -826,18 +842,21 @@ class StableDiffusionPipeline:
         latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                          guidance_rescale, n_img, cross_attention_kwargs, eta, num_inference_steps,
                                          sampler_opt, seed, start_time, timeout, input_hook=keep_known_region,
-                                         control_hook=control_hook, extra_input=extra_input)
+                                         control_hook=control_hook, extra_input=extra_input, preview=preview)
+        if latent_processing == 1:                               # :1759-1760
+            return latents_process
         return [self.latent_to_image(latents, output_type)]
 
     # ---- protocol mode: the reference's model_fn closure (:1091-1171) + sampler call (:1172-1175)
     def _denoise_protocol(self, sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                           guidance_rescale, n_img, cross_attention_kwargs, eta, steps, sampler_opt, seed, start_time,
-                          timeout, sampler_args=None, input_hook=None, control_hook=None, extra_input=None):
+                          timeout, sampler_args=None, input_hook=None, control_hook=None, extra_input=None, preview=None):
         """sampler_args: the keyword arguments for `sampler` when the caller built them itself (img2img's
         get_sampler_extra_args_i2i); input_hook(x, sigma, call_index) -> x: applied to the model input (inpainting's
         re-imposition of the known region, reference :1599-1612); extra_input [rows, c, h, w]: channels concatenated to the
         duplicated latent before the denoiser (the 9-channel inpainting UNet's mask + masked-image latents, :1617-1619 - the
-        denoiser's c_in then scales them too, as in the reference)"""
+        denoiser's c_in then scales them too, as in the reference); preview = (list, output_type): every model call appends the
+        image of its denoised estimate (`latent_processing == 1`, :1169-1170)"""
         cfg = self.do_classifier_free_guidance
         kdm = self.k_diffusion_model
         calls = [0]
@@ -885,6 +904,8 @@ class StableDiffusionPipeline:
                 # a = 0, b = 1, c = 0: d <- D = x - sigma (eps_u + g (eps_c - eps_u)); the "next input" it also writes is unused
                 ops.cfg_dpmpp2m_step(d, st["eps"], scratch, s, guidance_scale, 0.0, 1.0, 0.0, 1.0, 0.0, 1.0,
                                      st["x_in"], st["t"], st["sigma"])
+                if preview is not None:
+                    preview[0].append(self.latent_to_image(d, preview[1]))
                 return d.to(x.dtype)
 
             extra = sampler_args if sampler_args is not None else \
@@ -917,6 +938,8 @@ class StableDiffusionPipeline:
                 noise_pred = u + guidance_scale * (c - u)
                 if guidance_rescale > 0.0:
                     noise_pred = rescale_noise_cfg(noise_pred, c, guidance_rescale=guidance_rescale)
+            if preview is not None:
+                preview[0].append(self.latent_to_image(noise_pred, preview[1]))
             return noise_pred
 
         extra = sampler_args if sampler_args is not None else \

@@ -865,6 +865,10 @@ def test_img2img_and_inpainting_pipeline(ops):
     assert (inp - ref_i).abs().max().item() < 4e-2 * sc, ((inp - ref_i).abs().max().item(), sc)
     with pytest.raises(NotImplementedError):
         pipe.inpaiting(None, image=lat0, mask_image=mask, padding_mask_crop=8, **common)
+    # latent previews (reference :1083-1084, :1169-1170, :1229-1230): the start + one estimate per model call, nothing else
+    common["sampler_name"] = "sample_heun"
+    prev = pipe.txt2img(None, latents=lat0.clone(), latent_processing=1, **common)
+    assert len(prev) == 1 + (2 * steps - 1) and all(p_.shape == (1, 4, 16, 16) for p_ in prev)       # Heun: 2 calls per step but the last
     # hires pass (reference :1176-1228): txt2img, latents x1.5 by bicubic interpolation, img2img at strength 0.5
     common["sampler_name"] = "sample_dpmpp_2m"
     hi = pipe.txt2img(None, latents=lat0.clone(), upscale=True, upscale_x=1.5, upscale_denoising_strength=0.5,
