@@ -58,6 +58,9 @@ def parse():
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
                          "falls back to kernels >10x slower on this image; off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batched-roofline", action="store_true",
+                    help="skip roofline_at_8_images (profiling runs: its Bc = 16 launches of the same kernels would mix into the "
+                         "per-kernel averages of the rocprofv3 summary)")
     ap.add_argument("--decode", action="store_true",
                     help="also run the VAE decoder (SURVEY.md 8f rank 1) inside the timed region; off by default so the "
                          "headline stays the denoising path of BASELINE.json")
@@ -320,7 +323,7 @@ def main():
         res["roofline"] = roofline_region_xattn(dev, n_img)
         res["roofline_self_attn"] = roofline_self_attn(dev, n_img)
         res["roofline_conv3x3"] = roofline_conv3x3(dev, n_img)
-        if n_img == 1:
+        if n_img == 1 and not a.no_batched_roofline:
             # the same three kernels at the batch of BASELINE configs[2] (8 images per GPU, Bc = 16): what they reach once a
             # launch has enough workgroups to fill the chip - the bench workload above (Bc = 2) is launch-latency bound
             pick = lambda r: {k_: r[k_] for k_ in ("achieved", "unit", "frac", "avg_launch_us")}    # noqa: E731
