@@ -277,7 +277,9 @@ class _RegionProcessor:
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
                                     groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp)
         elif not is_self:
-            if S > _KERNEL_MAX_KEYS:              # long prompt without a region table: library attention
+            if S > _KERNEL_MAX_KEYS and q4.dtype == torch.float16 and d % 8 == 0 and d <= 160:
+                out = ops.self_attention(q4, k4, v4, scale=sc)      # long prompt without a region table: the flash kernel (S != L)
+            elif S > _KERNEL_MAX_KEYS:
                 out = F.scaled_dot_product_attention(q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2),
                                                      scale=sc).transpose(1, 2).contiguous()
             elif packed_kv is not None:
@@ -401,7 +403,9 @@ class _IPAdapterProcessor(_RegionProcessor, nn.Module):
             v4 = to_v_ip(cur).view(B, T, H, d)
             if T <= 96:
                 o = ops.region_xattn(q4, k4, v4, None, layout="blhd", scale=sc, ref_fp16_rounding=False)
-            else:                                     # long image-token sequences (257-token variants): library attention
+            elif q4.dtype == torch.float16 and d % 8 == 0 and d <= 160:
+                o = ops.self_attention(q4, k4, v4, scale=sc)          # 257-token variants (Full / Plus): the flash kernel, S != L
+            else:
                 o = F.scaled_dot_product_attention(q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2),
                                                    scale=sc).transpose(1, 2)
             o = o.reshape(B, L, H * d)

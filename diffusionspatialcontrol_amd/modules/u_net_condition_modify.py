@@ -44,6 +44,80 @@ class ImageProjection(nn.Module):
         return self.norm(self.image_embeds(image_embeds).reshape(b, self.num_image_text_embeds, -1))
 
 
+class _GeluFeedForward(nn.Module):
+    """diffusers `FeedForward(dim, dim_out, mult, activation_fn="gelu", bias=...)`: net.0.proj (Linear + exact GELU), net.1
+    Dropout(0), net.2 Linear - the key names of the IP-Adapter Full / Plus image projections"""
+
+    def __init__(self, dim, dim_out, mult, bias=True):
+        super().__init__()
+        inner = int(dim * mult)
+        self.net = nn.ModuleList([nn.ModuleDict({"proj": nn.Linear(dim, inner, bias=bias)}), nn.Dropout(0.0),
+                                  nn.Linear(inner, dim_out, bias=bias)])
+
+    def forward(self, x):
+        return self.net[2](F.gelu(self.net[0]["proj"](x)))
+
+
+class IPAdapterFullImageProjection(nn.Module):
+    """diffusers 0.27.2 `IPAdapterFullImageProjection` [recalled; package absent - parity unpinned]: CLIP penultimate hidden
+    states [B, T, image_embed_dim] -> LayerNorm(FeedForward(x)) [B, T, cross_attention_dim]"""
+
+    def __init__(self, image_embed_dim=1024, cross_attention_dim=1024):
+        super().__init__()
+        self.ff = _GeluFeedForward(image_embed_dim, cross_attention_dim, mult=1)
+        self.norm = nn.LayerNorm(cross_attention_dim)
+
+    def forward(self, image_embeds):
+        return self.norm(self.ff(image_embeds))
+
+
+class _ResamplerAttention(nn.Module):
+    """diffusers `Attention(query_dim, dim_head, heads, out_bias=False)` as the Plus resampler uses it: no biases, queries
+    from the latents, keys / values from [image tokens ; latents]"""
+
+    def __init__(self, dim, dim_head, heads):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads = heads
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(dim, inner, bias=False)
+        self.to_v = nn.Linear(dim, inner, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(inner, dim, bias=False), nn.Dropout(0.0)])
+
+    def forward(self, latents, context):
+        b, n, _ = latents.shape
+        sp = lambda t: t.reshape(b, t.shape[1], self.heads, -1).transpose(1, 2)  # noqa: E731
+        o = F.scaled_dot_product_attention(sp(self.to_q(latents)), sp(self.to_k(context)), sp(self.to_v(context)))
+        return self.to_out[0](o.transpose(1, 2).reshape(b, n, -1))
+
+
+class IPAdapterPlusImageProjection(nn.Module):
+    """diffusers 0.27.2 `IPAdapterPlusImageProjection` (the Perceiver-style Resampler of IP-Adapter Plus) [recalled; parity
+    unpinned]: `num_queries` learned latents attend to the projected image tokens and themselves for `depth` layers."""
+
+    def __init__(self, embed_dims=768, output_dims=1024, hidden_dims=1280, depth=4, dim_head=64, heads=16, num_queries=8,
+                 ffn_ratio=4):
+        super().__init__()
+        self.latents = nn.Parameter(torch.randn(1, num_queries, hidden_dims) / hidden_dims ** 0.5)
+        self.proj_in = nn.Linear(embed_dims, hidden_dims)
+        self.proj_out = nn.Linear(hidden_dims, output_dims)
+        self.norm_out = nn.LayerNorm(output_dims)
+        self.layers = nn.ModuleList([nn.ModuleList([
+            nn.LayerNorm(hidden_dims), nn.LayerNorm(hidden_dims), _ResamplerAttention(hidden_dims, dim_head, heads),
+            nn.Sequential(nn.LayerNorm(hidden_dims), _GeluFeedForward(hidden_dims, hidden_dims, ffn_ratio, bias=False))])
+            for _ in range(depth)])
+
+    def forward(self, x):
+        latents = self.latents.repeat(x.size(0), 1, 1)
+        x = self.proj_in(x)
+        for ln0, ln1, attn, ff in self.layers:
+            residual = latents
+            latents = ln1(latents)
+            latents = attn(latents, torch.cat([ln0(x), latents], dim=-2)) + residual
+            latents = ff(latents) + latents
+        return self.norm_out(self.proj_out(latents))
+
+
 class MultiIPAdapterImageProjection(nn.Module):
     """diffusers 0.27.2 `MultiIPAdapterImageProjection` [recalled]: one projection layer per loaded IP-Adapter; takes the
     list of per-adapter image embeddings ([B, num_images, D], or the deprecated single [B, D] tensor) and returns the
@@ -72,11 +146,46 @@ class UNet2DConditionLoadersMixin_modify:
     loader calls `_load_ip_adapter_weights` on it (ip_adapter.py:231) and expects the extra (FaceID) LoRAs back."""
 
     def _convert_ip_adapter_image_proj_to_diffusers(self, state_dict):
-        """standard IP-Adapter image projection only ("proj.weight" + "norm.*": Linear + LayerNorm -> 4 tokens); the
-        Plus / Full / FaceID resamplers are further 'next' rows"""
+        """(projection module, number of image tokens) from an IP-Adapter checkpoint's `image_proj` dict, by its keys [diffusers
+        0.27.2 `_convert_ip_adapter_image_proj_to_diffusers`, recalled]: "proj.weight" -> standard (Linear + LayerNorm, 4 tokens);
+        "proj.3.weight" -> Full (MLP + LayerNorm on the CLIP hidden states, 257 tokens); "latents" -> Plus (Resampler).  FaceID
+        ("norm.weight" + "proj.0/2" with LoRA weights) is not built."""
+        if "proj.3.weight" in state_dict:
+            proj = IPAdapterFullImageProjection(image_embed_dim=state_dict["proj.0.weight"].shape[0],
+                                                cross_attention_dim=state_dict["proj.3.weight"].shape[0])
+            ren = {"proj.0": "ff.net.0.proj", "proj.2": "ff.net.2", "proj.3": "norm"}
+            proj.load_state_dict({next((k.replace(a_, b_) for a_, b_ in ren.items() if k.startswith(a_)), k): v
+                                  for k, v in state_dict.items()})
+            return proj, 257
+        if "latents" in state_dict:
+            hidden = state_dict["latents"].shape[2]
+            proj = IPAdapterPlusImageProjection(embed_dims=state_dict["proj_in.weight"].shape[1],
+                                                output_dims=state_dict["proj_out.weight"].shape[0], hidden_dims=hidden,
+                                                heads=state_dict["layers.0.0.to_q.weight"].shape[0] // 64,
+                                                num_queries=state_dict["latents"].shape[1],
+                                                ffn_ratio=state_dict["layers.0.1.1.weight"].shape[0] / hidden,
+                                                depth=1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("layers.")))
+            sd = {}
+            for k, v in state_dict.items():
+                # original Resampler layout: layers.{i}.0 = PerceiverAttention (norm1, norm2, to_q, to_kv, to_out),
+                # layers.{i}.1 = FeedForward Sequential (0 LayerNorm, 1 Linear, 2 GELU, 3 Linear)
+                n = k.replace("0.to", "2.to").replace("1.0.weight", "3.0.weight").replace("1.0.bias", "3.0.bias")
+                n = n.replace("1.1.weight", "3.1.net.0.proj.weight").replace("1.3.weight", "3.1.net.2.weight")
+                if "norm1" in n:
+                    sd[n.replace("0.norm1", "0")] = v
+                elif "norm2" in n:
+                    sd[n.replace("0.norm2", "1")] = v
+                elif "to_kv" in n:
+                    kk, vv = v.chunk(2, dim=0)
+                    sd[n.replace("to_kv", "to_k")], sd[n.replace("to_kv", "to_v")] = kk, vv
+                elif "to_out" in n:
+                    sd[n.replace("to_out", "to_out.0")] = v
+                else:
+                    sd[n] = v
+            proj.load_state_dict(sd)
+            return proj, state_dict["latents"].shape[1]
         if "proj.weight" not in state_dict:
-            raise NotImplementedError("only the standard IP-Adapter image projection (proj + norm) is built; the "
-                                      "Resampler / Full / FaceID projections are not")
+            raise NotImplementedError("IP-Adapter FaceID image projections (and their LoRA weights) are not built")
         num_tokens = 4
         w = state_dict["proj.weight"]
         ctx = w.shape[0] // num_tokens

@@ -98,6 +98,19 @@ def test_self_attention(ops, B, H, L, d):
         assert (out2.float().cpu() - ref2).abs().max().item() < 3e-3
 
 
+@pytest.mark.parametrize("B,H,L,S,d", [(2, 8, 4096, 257, 40), (2, 8, 256, 257, 160), (1, 8, 1024, 77, 80), (2, 5, 64, 300, 64)])
+def test_attention_keys_differ_from_queries(ops, B, H, L, S, d):
+    """dsc_self_attn_fwd with S != L (a ragged last key tile): the IP-Adapter image-token attention of the 257-token variants"""
+    g = torch.Generator().manual_seed(L + S)
+    q = torch.randn(B, L, H, d, generator=g).half().cuda()
+    k = torch.randn(B, S, H, d, generator=g).half().cuda()
+    v = torch.randn(B, S, H, d, generator=g).half().cuda()
+    out = ops.self_attention(q, k, v)
+    ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2)
+    err = (out.float() - ref).abs()
+    assert out.shape == (B, L, H, d) and err.max().item() < 4e-3 and err.mean().item() < 3e-4, (err.max().item(), err.mean().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(8192, 320, 320), (8192, 960, 320), (8192, 320, 1280), (2048, 640, 640), (2048, 640, 2560),
                                    (512, 1280, 1280), (512, 3840, 1280), (300, 64, 64), (8192, 320, 960), (256, 1280, 5120)])
 def test_linear_kernel(ops, M, N, K):
