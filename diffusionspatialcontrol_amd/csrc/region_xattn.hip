@@ -326,11 +326,11 @@ int check_common(const void* q, const void* k, int Bc, int H, int L, int S, int 
 }  // namespace
 
 extern "C" size_t dsc_region_xattn_workspace_bytes(int Bc, int H, int L, int S, int d, int n_std_groups) {
-    (void)S; (void)d;
+    (void)d;
     if (Bc <= 0 || H <= 0 || L <= 0 || n_std_groups <= 0) return 0;
     XattnParams p{};
     p.Bc = Bc; p.H = H; p.L = L; p.n_groups = n_std_groups;
-    plan(p);
+    plan_tiles(p, S > kSMax ? 1 : 0);        // the long-prompt kernels (packed path, S > 96) run one tile per wave
     return (size_t)n_std_groups * p.npart * 2 * sizeof(double);
 }
 

@@ -43,9 +43,12 @@ __global__ __launch_bounds__(256) void xp_pack(const half_t* k, const half_t* v,
                                                long long vsh) {
     using P = PCfg<NK>;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const half_t* kb = k + b * ksb + h * ksh;
-    const half_t* vb = v + b * vsb + h * vsh;
-    half_t* dst = img + (long long)bh * P::IMG;
+    // key chunk blockIdx.y of gridDim.y (prompts longer than 96 keys: images [bh][chunk]); keys [96 c, min(S, 96 c + 96))
+    const int kc = blockIdx.y;
+    const half_t* kb = k + b * ksb + h * ksh + (long long)kc * kSMax * kss;
+    const half_t* vb = v + b * vsb + h * vsh + (long long)kc * kSMax * vss;
+    half_t* dst = img + ((long long)bh * gridDim.y + kc) * P::IMG;
+    S = min(S - kc * kSMax, kSMax);
     for (int idx = threadIdx.x; idx < (P::KFR + P::VFR) * 64; idx += 256) {
         const int f = idx >> 6, lane = idx & 63, r = lane & 31, hh = lane >> 5;
         h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -278,6 +281,214 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- long prompts (S > 96)
+// Prompts of several 77-token chunks (A1111-style / lpw-style long prompts: S = 154, 231, ...) keep the same two-phase
+// method: the key axis is cut into chunks of 96 keys, each with its own packed image [bh][chunk]; the statistics kernel
+// sums over all chunks, the forward kernel walks the chunks with an ONLINE softmax (running max / sum per query row, the
+// output accumulators rescaled when the max grows) - scores stay fp32 (no fp16-rounding emulation on this path).
+// One 32-row tile per wave (tiles_per_wave = 1); the image of a chunk is DMA'd into one LDS buffer per chunk step.
+constexpr int kChunksMax = 4;    // S <= 384
+
+template <int NK>
+__global__ __launch_bounds__(kThreads, 2) void xp_stats_long(XpParams pp, int nkc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using P = PCfg<NK>;
+    const XattnParams& p = pp.x;
+    half_t* img = reinterpret_cast<half_t*>(smem);
+    double* red = reinterpret_cast<double*>(smem + P::KFR * 1024);
+    int b, h, chunk;
+    block_to_work(p, b, h, chunk);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+    const int l0 = (chunk * kWaves + wave) * 32;
+    const bool tile_ok = l0 < p.L, row_ok = l0 + r < p.L;
+    h8_t qf[NK];
+    load_q_frags<NK>(p, qf, b, h, min(l0 + r, p.L - 1), hh);
+    double d1 = 0.0, d2 = 0.0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc > 0) __syncthreads();                         // every wave is done reading the previous chunk's image
+        dma_image(pp.img + ((long long)(b * p.H + h) * nkc + kc) * P::IMG, smem, P::KFR, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile_ok) {
+            const int valid = min(p.S - kc * kSMax, kSMax);
+            XattnParams pc = p;
+            pc.S = valid;
+            f16x_t acc[3];
+            scores_img<NK, false>(pc, img, qf, acc, lane, p.scale);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int s_ = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const float a = (row_ok && s_ < valid) ? acc[m][i] : 0.f;
+                    s1 += a;
+                    s2 += a * a;
+                }
+            d1 += (double)s1; d2 += (double)s2;
+        }
+    }
+    d1 = wave_sum_f64(d1);
+    d2 = wave_sum_f64(d2);
+    if (lane == 0) { red[2 * wave] = d1; red[2 * wave + 1] = d2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a1 = 0.0, a2 = 0.0;
+        for (int w = 0; w < kWaves; ++w) { a1 += red[2 * w]; a2 += red[2 * w + 1]; }
+        const int g = b % p.n_groups;
+        const int idx = ((b / p.n_groups) * p.H + h) * p.nchunks + chunk;
+        double* dst = p.partials + ((long long)g * p.npart + idx) * 2;
+        dst[0] = a1; dst[1] = a2;
+    }
+}
+
+// one chunk of the online softmax: acc holds the raw scores of <= 96 keys (`valid` of them real); m_run / l_run the running
+// row maximum (log2 domain) and sum; returns the factor the output accumulators are rescaled by; pf = exp2(a - m_new)
+__device__ __forceinline__ float softmax_chunk_online(f16x_t (&acc)[3], h8_t (&pf)[6], const float* brow, float scale_log2e,
+                                                      int valid, int hh, float& m_run, float& l_run) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (brow) bias4<true>(brow, 32 * m + 8 * g + 4 * hh, valid - 1, bias);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * g + j, s_ = 32 * m + 8 * g + 4 * hh + j;
+                float a = acc[m][i] * scale_log2e;
+                if (brow) a = fmaf(bias[j], kLog2e, a);
+                a = s_ < valid ? a : -INFINITY;
+                acc[m][i] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);                    // finite: every chunk holds at least one real key
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first chunk: exp2(-inf) = 0
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(acc[m][i] - m_new);
+            acc[m][i] = e;
+            sum += e;
+        }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)acc[m][i];
+    sum += __shfl_xor(sum, 32, 64);
+    l_run = l_run * alpha + sum;
+    m_run = m_new;
+    return alpha;
+}
+
+template <int NK>
+__global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd_long(XpParams pp, int nkc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using P = PCfg<NK>;
+    constexpr int DM = P::DM;
+    const XattnParams& p = pp.x;
+    half_t* img = reinterpret_cast<half_t*>(smem);
+    float* biasT = reinterpret_cast<float*>(smem + P::IMG * 2);          // [NU][nkc * kBP]
+    double* red = reinterpret_cast<double*>(biasT + kNUMax * kChunksMax * kBP);
+    int b, h, chunk;
+    block_to_work(p, b, h, chunk);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
+    const bool has_bias = pp.ids != nullptr;
+    const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;
+    const int l0 = (chunk * kWaves + wave) * 32;
+    const bool tile_ok = l0 < p.L, row_ok = l0 + r < p.L;
+    const int row = tile_ok ? min(l0 + r, p.L - 1) : 0;
+    const int rs = nkc * kBP;                                             // bias-table row stride (floats)
+    h8_t qf[NK];
+    int id = 0;
+    if (tile_ok) {
+        load_q_frags<NK>(p, qf, b, h, row, hh);
+        if (has_bias) id = pp.ids[(long long)bw * p.L + row];
+    }
+    if (has_bias) {
+        const float sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
+        const float sd = group_std(p, b % p.n_groups, red, false);        // contains __syncthreads()
+        for (int idx = threadIdx.x; idx < pp.NU * rs; idx += kThreads) {  // w * sigma * std, zero padded past each chunk's keys
+            const int u = idx / rs, rem = idx - u * rs, kc = rem / kBP, s_ = rem - kc * kBP;
+            const int key = kc * kSMax + s_;
+            biasT[idx] = (s_ < kSMax && key < p.S) ? (pp.rows[(long long)u * p.S + key] * sig) * sd : 0.f;
+        }
+    }
+    f16x_t o[DM];
+#pragma unroll
+    for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dm][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+        if (kc > 0) __syncthreads();                         // the previous chunk's fragments are all in registers / consumed
+        dma_image(pp.img + ((long long)(b * p.H + h) * nkc + kc) * P::IMG, smem, P::KFR + P::VFR, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // image landed; (first pass) bias table complete
+        if (!tile_ok) continue;
+        const int valid = min(p.S - kc * kSMax, kSMax);
+        XattnParams pc = p;
+        pc.S = valid;
+        f16x_t acc[3];
+        scores_img<NK, false, true>(pc, img, qf, acc, lane, p.scale);
+        h8_t pf[6];
+        const float* brow = has_bias ? biasT + id * rs + kc * kBP : nullptr;
+        const float alpha = softmax_chunk_online(acc, pf, brow, p.scale * 1.4426950408889634f, valid, hh, m_run, l_run);
+        const int nt = (valid + 15) >> 4;
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm) {
+            if (32 * dm < p.d) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    if (tt < nt) {
+                        const h8_t vf = *reinterpret_cast<const h8_t*>(img + ((P::KFR + dm * 6 + tt) * 64 + lane) * 8);
+                        o[dm] = mfma_32x32x16(vf, pf[tt], o[dm]);
+                    }
+                }
+            }
+        }
+    }
+    if (tile_ok && row_ok) {
+        const float inv = 1.f / l_run;
+        half_t* ob = p.out + b * p.osb + h * p.osh + (long long)row * p.osl;
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                if (dd0 < p.d) {
+                    const h4_t ov = {(half_t)(o[dm][4 * g4] * inv), (half_t)(o[dm][4 * g4 + 1] * inv),
+                                     (half_t)(o[dm][4 * g4 + 2] * inv), (half_t)(o[dm][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<h4_t*>(ob + dd0) = ov;
+                }
+            }
+    }
+}
+
+template <int NK>
+int launch_packed_long(const XpParams& pp, int nkc, bool need_stats, hipStream_t st) {
+    using P = PCfg<NK>;
+    const dim3 grid = xattn_grid(pp.x), block(kThreads);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xp_fwd_long<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xp_stats_long<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (need_stats) DSC_LAUNCH((xp_stats_long<NK>), grid, block, (size_t)P::KFR * 1024 + kRedBytes, st, pp, nkc);
+    const size_t lds = (size_t)P::IMG * 2 + (size_t)kNUMax * kChunksMax * kBP * 4 + kRedBytes;
+    DSC_LAUNCH((xp_fwd_long<NK>), grid, block, lds, st, pp, nkc);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}
+
 int pick_nk(int d) {
     static const int opts[] = {2, 3, 4, 5, 6, 8, 10};
     for (int nk : opts) if (16 * nk >= d) return nk;
@@ -298,7 +509,7 @@ size_t img_bytes_nk(int nk) {
 template <int NK>
 int launch_pack(const half_t* k, const half_t* v, half_t* img, int Bc, int H, int S, int d, const int64_t* ks,
                 const int64_t* vs, hipStream_t st) {
-    DSC_LAUNCH(xp_pack<NK>, dim3(Bc * H), dim3(256), 0, st, k, v, img, H, S, d, (long long)ks[0], (long long)ks[1],
+    DSC_LAUNCH(xp_pack<NK>, dim3(Bc * H, (S + kSMax - 1) / kSMax), dim3(256), 0, st, k, v, img, H, S, d, (long long)ks[0], (long long)ks[1],
                        (long long)ks[2], (long long)vs[0], (long long)vs[1], (long long)vs[2]);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
@@ -340,6 +551,9 @@ int dispatch_pack(int nk, const half_t* k, const half_t* v, half_t* img, int Bc,
                   const int64_t* vs, hipStream_t st) {
     DSC_NK_SWITCH(nk, launch_pack, >(k, v, img, Bc, H, S, d, ks, vs, st))
 }
+int dispatch_packed_long(int nk, const XpParams& pp, int nkc, bool need_stats, hipStream_t st) {
+    DSC_NK_SWITCH(nk, launch_packed_long, >(pp, nkc, need_stats, st))
+}
 int dispatch_packed(int nk, bool ref16, const XpParams& pp, bool need_stats, hipStream_t st) {
     if (ref16) { DSC_NK_SWITCH(nk, launch_packed, COMMA_TRUE>(pp, need_stats, st)) }
     DSC_NK_SWITCH(nk, launch_packed, COMMA_FALSE>(pp, need_stats, st))
@@ -354,14 +568,14 @@ static void* g_debug_stamps = nullptr;
 extern "C" void dsc_debug_set_stamp_buffer(void* device_buffer_2KiB) { g_debug_stamps = device_buffer_2KiB; }
 
 extern "C" size_t dsc_xattn_kv_pack_bytes(int Bc, int H, int S, int d) {
-    if (Bc <= 0 || H <= 0 || S <= 0 || S > kSMax || d <= 0 || d % 8 != 0 || d > 160) return 0;
-    return (size_t)Bc * H * img_bytes_nk(pick_nk(d));
+    if (Bc <= 0 || H <= 0 || S <= 0 || S > kSMax * kChunksMax || d <= 0 || d % 8 != 0 || d > 160) return 0;
+    return (size_t)Bc * H * ((S + kSMax - 1) / kSMax) * img_bytes_nk(pick_nk(d));
 }
 
 extern "C" int dsc_xattn_kv_pack(const void* k, const void* v, void* packed, int Bc, int H, int S, int d,
                                  const int64_t k_strides[3], const int64_t v_strides[3], int dtype, void* stream) {
     if (!k || !v || !packed || !k_strides || !v_strides || Bc <= 0 || H <= 0 || S <= 0 || d <= 0) return DSC_ERR_BAD_ARG;
-    if (dtype != DSC_F16 || d % 8 != 0 || d > 160 || S > kSMax) return DSC_ERR_UNSUPPORTED;
+    if (dtype != DSC_F16 || d % 8 != 0 || d > 160 || S > kSMax * kChunksMax) return DSC_ERR_UNSUPPORTED;
     if (!aligned16(k) || !aligned16(v) || !aligned16(packed) || !strides_ok(k_strides) || !strides_ok(v_strides))
         return DSC_ERR_UNSUPPORTED;
     return dispatch_pack(pick_nk(d), static_cast<const half_t*>(k), static_cast<const half_t*>(v),
@@ -376,7 +590,9 @@ extern "C" int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv,
                                            unsigned flags, void* workspace, size_t workspace_bytes, void* stream) {
     if (!q || !packed_kv || !out || !q_strides || !o_strides) return DSC_ERR_BAD_ARG;
     if (Bc <= 0 || H <= 0 || L <= 0 || S <= 0 || d <= 0 || n_std_groups <= 0 || Bc % n_std_groups != 0) return DSC_ERR_BAD_ARG;
-    if (dtype != DSC_F16 || d % 8 != 0 || d > 160 || S > kSMax) return DSC_ERR_UNSUPPORTED;
+    if (dtype != DSC_F16 || d % 8 != 0 || d > 160 || S > kSMax * kChunksMax) return DSC_ERR_UNSUPPORTED;
+    const int nkc = (S + kSMax - 1) / kSMax;                 // key chunks: > 1 = the long-prompt kernels (fp32 scores only)
+    if (nkc > 1 && (flags & DSC_FLAG_REF_FP16_ROUNDING)) return DSC_ERR_UNSUPPORTED;
     if (!aligned16(q) || !aligned16(packed_kv) || (reinterpret_cast<uintptr_t>(out) & 7) || !strides_ok(q_strides) ||
         !strides_ok(o_strides))
         return DSC_ERR_UNSUPPORTED;
@@ -394,7 +610,7 @@ extern "C" int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv,
     p.qsb = q_strides[0]; p.qsl = q_strides[1]; p.qsh = q_strides[2];
     p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
     p.flags = flags;
-    plan_tiles(p);
+    plan_tiles(p, nkc > 1 ? 1 : 0);
     p.std_out = static_cast<float*>(g_debug_stamps);
     pp.img = static_cast<const half_t*>(packed_kv);
     pp.ids = region_ids; pp.rows = region_rows; pp.NU = has_bias ? n_rows : 0;
@@ -404,6 +620,7 @@ extern "C" int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv,
         p.partials = static_cast<double*>(workspace);
     }
     const bool need_stats = has_bias && !(flags & DSC_FLAG_REUSE_STATS);
+    if (nkc > 1) return dispatch_packed_long(pick_nk(d), pp, nkc, need_stats, static_cast<hipStream_t>(stream));
     return dispatch_packed(pick_nk(d), (flags & DSC_FLAG_REF_FP16_ROUNDING) != 0, pp, need_stats,
                            static_cast<hipStream_t>(stream));
 }

@@ -150,9 +150,22 @@ def _region_attention_long(q, k, v, w, sigma, weight_func, layout, n_std_groups,
     return out if layout == "bhld" else out.transpose(1, 2).contiguous()
 
 
+_KERNEL_MAX_KEYS_PACKED = 384   # region_xattn_packed.hip kChunksMax x 96: long prompts (77 n tokens) on the chunked kernels
+
+
 def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None,
                       comp=None):
-    if k.shape[2 if layout == "bhld" else 1] > _KERNEL_MAX_KEYS:
+    S = k.shape[2 if layout == "bhld" else 1]
+    if S > _KERNEL_MAX_KEYS:
+        # long prompts: the prepared-operand kernels walk the keys in chunks of 96 with an online softmax (fp32 scores, default
+        # weight_func, compressible table); anything else runs the reference's op sequence as library kernels
+        if (S <= _KERNEL_MAX_KEYS_PACKED and packed_kv is not None and layout == "blhd" and not ref16
+                and (weight_func is None or weight_func_is_default(weight_func))):
+            if comp is None:
+                comp = compressed_table(w, q.device)
+            if comp is not None:
+                return ops.region_xattn_packed(q, packed_kv, S, comp, _sigma_arg(sigma, q.device), n_std_groups=n_std_groups,
+                                               scale=scale, ref_fp16_rounding=False)
         return _region_attention_long(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale)
     if weight_func is None or weight_func_is_default(weight_func):
         if packed_kv is not None and layout == "blhd":

@@ -1083,7 +1083,7 @@ class StableDiffusionPipeline:
                 else:
                     c = m.kv_cache = {"src": text, "k": k, "v": v, "packed": None}
                 # MFMA-fragment image of K / V^T for the fused kernel (rewritten in place: captured graphs keep reading it)
-                if S <= 96 and d % 8 == 0 and d <= 160:
+                if S <= 384 and d % 8 == 0 and d <= 160:          # > 96 keys: one image per 96-key chunk (long prompts)
                     c["packed"] = ops.xattn_kv_pack(c["k"].view(B, S, m.heads, d), c["v"].view(B, S, m.heads, d),
                                                     out=c.get("packed"))
 

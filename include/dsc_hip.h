@@ -116,6 +116,9 @@ int dsc_region_xattn_std(const void* q, const void* k,
  *                 at most 2^regions distinct rows, encode_region_map_function.py:49-69).
  * The forward kernel DMAs the image into LDS (global_load_lds) and folds sigma * std into an LDS bias table once per
  * workgroup.  Flags: DSC_FLAG_REF_FP16_ROUNDING, DSC_FLAG_REUSE_STATS.  Workspace as dsc_region_xattn_workspace_bytes().
+ * S <= 96: one image per (b, h).  96 < S <= 384 (prompts of several 77-token chunks, encoder_prompt_modify.py:691-812): one
+ * image per (b, h, 96-key chunk); the statistics run over all chunks, the forward pass walks them with an online softmax;
+ * fp32 scores only (DSC_FLAG_REF_FP16_ROUNDING -> DSC_ERR_UNSUPPORTED).
  */
 size_t dsc_xattn_kv_pack_bytes(int Bc, int H, int S, int d);
 int dsc_xattn_kv_pack(const void* k, const void* v, void* packed, int Bc, int H, int S, int d,

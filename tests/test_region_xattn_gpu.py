@@ -209,6 +209,35 @@ def test_packed_path_equals_generic_and_oracle(ops, Bc, H, L, S, d, Bw, ng):
     assert torch.equal(out0.transpose(1, 2), gen0)
 
 
+LONG_SHAPES = [(2, 8, 4096, 154, 40, 2, 1), (2, 8, 1024, 231, 80, 2, 1), (2, 8, 256, 154, 160, 2, 1), (2, 8, 64, 231, 160, 2, 1),
+               (4, 8, 1024, 154, 40, 4, 2), (2, 10, 512, 308, 64, 2, 1), (2, 2, 70, 97, 8, 1, 1), (2, 4, 100, 384, 16, 2, 1)]
+
+
+@pytest.mark.parametrize("Bc,H,L,S,d,Bw,ng", LONG_SHAPES)
+def test_long_prompt_chunked_kernels(ops, Bc, H, L, S, d, Bw, ng):
+    """Prompts of several 77-token chunks (S = 154, 231, 308 ...; > 96 keys): the prepared-operand kernels walk the keys in
+    chunks of 96 with an online softmax; global std over ALL keys.  Against the fp32 oracle (no fp16-rounding emulation on this
+    path), with and without a region table, bit-reproducible."""
+    x = attn_inputs(f"long/{Bc}/{H}/{L}/{S}/{d}", Bc=Bc, H=H, L=L, S=S, d=d, Bw=Bw)
+    q, k, v, w = (torch.from_numpy(x[n]) for n in ("q", "k", "v", "w"))
+    w[:, :, 100:104] += torch.from_numpy(x["w"][:, :, 2:3]) * 0.5 if S > 104 else 0.0     # bias in the later chunks too
+    qd, kd, vd = q.cuda().half(), k.cuda().half(), v.cuda().half()
+    packed = ops.xattn_kv_pack(kd, vd, layout="bhld")
+    comp = ops.compress_region_table(w.cuda())
+    assert comp is not None
+    q_blhd = qd.transpose(1, 2)
+    out = ops.region_xattn_packed(q_blhd, packed, S, comp, 2.0, n_std_groups=ng, ref_fp16_rounding=False)
+    exp = ra.region_attention(q, k, v, w, 2.0, n_std_groups=ng)
+    err = (out.transpose(1, 2).float().cpu() - exp).abs()
+    assert err.max().item() < ATOL32 and err.mean().item() < 4e-4, (err.max().item(), err.mean().item())
+    assert torch.equal(out, ops.region_xattn_packed(q_blhd, packed, S, comp, 2.0, n_std_groups=ng, ref_fp16_rounding=False))
+    out0 = ops.region_xattn_packed(q_blhd, packed, S, None, ref_fp16_rounding=False)
+    ref0 = torch.softmax((q @ k.transpose(-2, -1)) / math.sqrt(d), dim=-1) @ v
+    assert (out0.transpose(1, 2).float().cpu() - ref0).abs().max().item() < ATOL32
+    with pytest.raises(Exception):
+        ops.region_xattn_packed(q_blhd, packed, S, comp, 2.0, n_std_groups=ng, ref_fp16_rounding=True)   # emulation: <= 96 keys only
+
+
 def test_compress_region_table_refuses_dense_tables(ops):
     w = torch.randn(2, 64, 77).cuda()
     assert ops.compress_region_table(w) is None
