@@ -5,10 +5,13 @@
 // hand-written gemm_tn_f16 does not cover (M <= 512 rows or K > 640: FF output projections, the low-resolution levels'
 // proj_out / conv_shortcut): torch offers either the bias epilogue (F.linear) or beta*C (addmm), never both, so each of
 // the 33 such GEMMs per UNet step was followed by a separate elementwise add launch.  hipBLASLt is a plain library GEMM
-// here (column-major view: D^T[N x M] = W[N x K] . X^T[K x M], bias along D^T's rows = output channels).
+// here (column-major view: D^T[N x M] = W[N x K] . X^T[K x M], bias along D^T's rows = output channels).  The one choice
+// made on top of it: which of the heuristic's candidate algorithms runs - the first call of a shape times up to DSC_LT_TUNE (default 16) of them
+// on the caller's operands and keeps the fastest (DSC_LT_TUNE=0: the heuristic's first choice, as torch takes it).
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -16,10 +19,25 @@
 
 namespace {
 
+constexpr int kMaxCand = 64;
+
+// DSC_LT_TUNE = number of heuristic candidates timed per shape (default 16, at most kMaxCand; 0 or 1 = no timing)
+int tune_count() {
+    static const int n = [] {
+        const char* e = getenv("DSC_LT_TUNE");
+        const int v = e ? atoi(e) : 16;
+        return v < 1 ? 1 : (v > kMaxCand ? kMaxCand : v);
+    }();
+    return n;
+}
+
 struct Plan {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
     hipblasLtMatmulAlgo_t algo;
+    hipblasLtMatmulAlgo_t cand[kMaxCand];         // the heuristic's ranking; the first call of a shape times them (tune_plan)
+    int n_cand = 0;
+    bool tuned = false;
     size_t ws = 0;
     bool ok = false;
 };
@@ -50,15 +68,48 @@ bool build_plan(Plan& p, int64_t M, int N, int K, int64_t ldx, int64_t ldr, int6
     if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
     const uint64_t maxws = kWsBytes;
     hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
-    hipblasLtMatmulHeuristicResult_t r[1];
+    hipblasLtMatmulHeuristicResult_t r[kMaxCand];
     int n = 0;
-    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, 1, r, &n);
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, tune_count(), r, &n);
     hipblasLtMatmulPreferenceDestroy(pref);
-    if (st != HIPBLAS_STATUS_SUCCESS || n < 1 || r[0].state != HIPBLAS_STATUS_SUCCESS) return false;
-    p.algo = r[0].algo;
-    p.ws = r[0].workspaceSize;
-    p.ok = p.ws <= kWsBytes;
-    return p.ok;
+    if (st != HIPBLAS_STATUS_SUCCESS || n < 1) return false;
+    for (int i = 0; i < n; ++i)
+        if (r[i].state == HIPBLAS_STATUS_SUCCESS && r[i].workspaceSize <= kWsBytes) p.cand[p.n_cand++] = r[i].algo;
+    if (p.n_cand < 1) return false;
+    p.algo = p.cand[0];
+    p.ok = true;
+    return true;
+}
+
+// Times the heuristic's candidates on the caller's own operands and keeps the fastest (the ranking is a model, not a
+// measurement: at these sizes - a few hundred token rows, K up to 5120 - its first choice is not always the best one).
+// Skipped while the stream is being captured and when the residual aliases the output (a re-run would accumulate).
+void tune_plan(Plan& p, const void* x, const void* w, const void* residual, void* out, hipStream_t stream) {
+    p.tuned = true;
+    if (p.n_cand < 2 || residual == out) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { p.tuned = false; return; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
+    const float alpha = 1.f, beta = residual ? 1.f : 0.f;
+    const void* c = residual ? residual : out;
+    float best = 1e30f;
+    constexpr int kWarm = 2, kRuns = 8;
+    for (int i = 0; i < p.n_cand; ++i) {
+        bool good = true;
+        for (int r = 0; r < kWarm + kRuns && good; ++r) {
+            if (r == kWarm) (void)hipEventRecord(e0, stream);
+            good = hipblasLtMatmul(g_handle, p.desc, &alpha, w, p.a, x, p.b, &beta, c, p.c, out, p.d, &p.cand[i], g_ws,
+                                   kWsBytes, stream) == HIPBLAS_STATUS_SUCCESS;
+        }
+        (void)hipEventRecord(e1, stream);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || !good || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) continue;
+        if (ms < best) { best = ms; p.algo = p.cand[i]; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
 }
 
 }  // namespace
@@ -90,6 +141,10 @@ extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias,
     if (bias) {
         // the descriptor is shared by every call of this shape: set the pointer right before the launch (single-stream use)
         hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    }
+    if (!plan->tuned) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!plan->tuned) tune_plan(*plan, x, w, residual, out, static_cast<hipStream_t>(stream));
     }
     const float alpha = 1.f, beta = residual ? 1.f : 0.f;
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta,

@@ -272,6 +272,7 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
 
 
 USE_LT_RESIDUAL = os.environ.get("DSC_LT_RESIDUAL", "1") != "0"   # GEMMs left to hipBLASLt take bias + residual in the same launch (dsc_linear_lt_f16)
+USE_LT_ALL = os.environ.get("DSC_LT_ALL", "1") != "0"   # ... and the ones without a residual go the same way (measured algorithm choice, DSC_LT_TUNE)
 USE_DSC_GEMM = True        # route qualifying linears to dsc_linear_f16 (False: always hipBLASLt through torch)
 DSC_GEMM_MIN_ROWS = 1024   # measured (tools/mb_gemm.py): the 128x64x64-tile kernel beats hipBLASLt + separate epilogue
 DSC_GEMM_MAX_K = 640       # kernels for >= 1024 token rows and K <= 640; hipBLASLt's larger macro-tiles win beyond
@@ -353,17 +354,22 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
         r2 = residual.reshape(M, N)
         ok = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
     if not ok:
-        if residual is not None and not geglu and USE_LT_RESIDUAL and x.dtype == torch.float16 and K % 8 == 0 and N % 8 == 0:
-            # library GEMM with the bias epilogue AND the residual as beta*C: one launch instead of GEMM + add
+        if ((USE_LT_RESIDUAL if residual is not None else USE_LT_ALL) and x.dtype == torch.float16 and K % 8 == 0
+                and N % 8 == 0 and M >= 8 and not (geglu and residual is not None)):
+            # library GEMM with the bias epilogue AND the residual as beta*C: one launch instead of GEMM + add; the
+            # algorithm is the fastest of the heuristic's candidates, timed on the first call of a shape
             xl = x.reshape(M, K)
-            rl = residual.reshape(M, N)
-            if (xl.stride(1) == 1 and rl.stride(1) == 1 and xl.stride(0) % 8 == 0 and rl.stride(0) % 8 == 0
-                    and weight.is_contiguous() and weight.dtype == torch.float16):
+            rl = residual.reshape(M, N) if residual is not None else None
+            if (xl.stride(1) == 1 and xl.stride(0) % 8 == 0 and weight.is_contiguous() and weight.dtype == torch.float16
+                    and (bias is None or bias.dtype == torch.float16)
+                    and (rl is None or (rl.stride(1) == 1 and rl.stride(0) % 8 == 0))):
                 out = torch.empty((M, N), dtype=x.dtype, device=x.device)
                 rc = _lib.load_library().dsc_linear_lt_f16(_p(xl), _p(weight), _p(bias), _p(rl), _p(out), M, N, K,
-                                                           xl.stride(0), rl.stride(0), N, 0, _stream_ptr(x))
+                                                           xl.stride(0), rl.stride(0) if rl is not None else 0, N, 0,
+                                                           _stream_ptr(x))
                 if rc == 0:
-                    return out.reshape(*lead, N)
+                    out = out.reshape(*lead, N)
+                    return globals()["geglu"](out) if geglu else out
         y = torch.nn.functional.linear(x, weight, bias)
         if geglu:
             return globals()["geglu"](y)
