@@ -30,7 +30,20 @@ struct GnN {
     int inline_stats;                                 // 1: the apply workgroups reduce the chunk partials themselves (no finalize launch)
     long long add_stride;
     float eps; int silu;
+    // concatenation mode (dsc_groupnorm_silu_nhwc_cat): the input is the channel concatenation [x | x2] (C1 channels from
+    // x, C - C1 from x2) that was never materialised; the pass that reads the sources also writes it to `cat`
+    const half_t* x2; half_t* cat; int C1;
 };
+
+// element (b, pix, channel c .. c+7) of the input; in concatenation mode read from the source that holds c and copied to cat
+__device__ __forceinline__ h8_t gn_load(const GnN& p, int b, int pix, int c) {
+    const long long bp = (long long)b * p.HW + pix;
+    if (!p.x2) return *reinterpret_cast<const h8_t*>(p.x + bp * p.C + c);
+    const h8_t v = c < p.C1 ? *reinterpret_cast<const h8_t*>(p.x + bp * p.C1 + c)
+                            : *reinterpret_cast<const h8_t*>(p.x2 + bp * (p.C - p.C1) + (c - p.C1));
+    *reinterpret_cast<h8_t*>(p.cat + bp * p.C + c) = v;
+    return v;
+}
 
 __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,9 +60,19 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) ad[j] = (float)a[j];
     }
+    // this thread's channel vector lives in one source for all rows: (base, row stride) fixed up front
     const half_t* base = p.x + (long long)b * p.HW * p.C + c8 * 8;
+    int rs = p.C;
+    half_t* cdst = nullptr;
+    if (p.x2) {
+        const int c2 = p.C - p.C1;
+        if (c8 * 8 < p.C1) { base = p.x + (long long)b * p.HW * p.C1 + c8 * 8; rs = p.C1; }
+        else { base = p.x2 + (long long)b * p.HW * c2 + (c8 * 8 - p.C1); rs = c2; }
+        cdst = p.cat + (long long)b * p.HW * p.C + c8 * 8;
+    }
     for (int row = r0 + slice; row < r1; row += p.k) {
-        const h8_t v = *reinterpret_cast<const h8_t*>(base + (long long)row * p.C);
+        const h8_t v = *reinterpret_cast<const h8_t*>(base + (long long)row * rs);
+        if (cdst) *reinterpret_cast<h8_t*>(cdst + (long long)row * p.C) = v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + ad[j]; s[j] += f; q[j] += f * f; }
     }
@@ -187,7 +210,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
         const int idx = threadIdx.x + 256 * i;
         if (idx < nvec) {
             const int pix = idx / vpp, j8 = idx - pix * vpp;
-            const h8_t x = *reinterpret_cast<const h8_t*>(p.x + base + (long long)pix * p.C + j8 * 8);
+            const h8_t x = gn_load(p, b, pix, g * p.cpg + j8 * 8);
             h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
             if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + g * p.cpg + j8 * 8);
 #pragma unroll
@@ -434,13 +457,38 @@ extern "C" size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int g
     return (size_t)B * p.anchunk * groups * 2 * sizeof(double) + (size_t)B * groups * 2 * sizeof(float);
 }
 
+namespace {
+int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, const void* gamma, const void* beta, const void* add,
+                  int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream);
+}
+
 extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, const void* add,
                                        int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
                                        void* workspace, size_t workspace_bytes, void* stream) {
+    return run_groupnorm(x, nullptr, 0, nullptr, y, gamma, beta, add, add_row_stride, B, C, hw, groups, eps, apply_silu, dtype,
+                         workspace, workspace_bytes, stream);
+}
+
+extern "C" int dsc_groupnorm_silu_nhwc_cat(const void* x1, const void* x2, int C1, void* cat, void* y, const void* gamma,
+                                           const void* beta, const void* add, int64_t add_row_stride, int B, int C, int hw,
+                                           int groups, float eps, int apply_silu, int dtype, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (!x2 || !cat || C1 <= 0 || C1 >= C) return DSC_ERR_BAD_ARG;
+    if (C1 % 8 != 0 || !al16(x2) || !al16(cat) || cat == x1 || cat == x2 || cat == y) return DSC_ERR_UNSUPPORTED;
+    return run_groupnorm(x1, x2, C1, cat, y, gamma, beta, add, add_row_stride, B, C, hw, groups, eps, apply_silu, dtype,
+                         workspace, workspace_bytes, stream);
+}
+
+namespace {
+int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, const void* gamma, const void* beta, const void* add,
+                  int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !y || !gamma || !beta || B <= 0 || C <= 0 || hw <= 0 || groups <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
     GnN p{};
     p.B = B; p.C = C; p.HW = hw; p.G = groups;
+    p.x2 = static_cast<const half_t*>(x2); p.cat = static_cast<half_t*>(cat); p.C1 = C1;
     if (!plan(p)) return DSC_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta) || (add && (!al16(add) || add_row_stride % 8 != 0 || add_row_stride < C)))
         return DSC_ERR_UNSUPPORTED;
@@ -462,11 +510,11 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
         // one workgroup streams a whole (image, bundle) slab: it wins only while the slab is small (measured,
         // tools/mb_gn.py: 1280 vectors 9.8 us vs 11.9 us for three launches; 3840 vectors 17.9 vs 12.6)
         GnBundle q{};
-        if (g_gn_mode < 2 && bundle_plan(p, 256, 16, &q) && (long long)p.HW * q.nvec <= 1536) {
+        if (g_gn_mode < 2 && !p.x2 && bundle_plan(p, 256, 16, &q) && (long long)p.HW * q.nvec <= 1536) {
             DSC_LAUNCH((gn_nhwc_bundle<256, 16>), dim3(B * (groups / q.gb)), dim3(256), (size_t)256 * 8 * sizeof(float), st, p, q);
             return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
         }
-        if (g_gn_mode == 3 && bundle_plan(p, 1024, 16, &q)) {       // diagnostics only: slower than three launches
+        if (g_gn_mode == 3 && !p.x2 && bundle_plan(p, 1024, 16, &q)) {       // diagnostics only: slower than three launches
             DSC_LAUNCH((gn_nhwc_bundle<1024, 16>), dim3(B * (groups / q.gb)), dim3(1024), (size_t)1024 * 8 * sizeof(float), st, p, q);
             return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
         }
@@ -482,6 +530,8 @@ extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma
     }
     DSC_LAUNCH(gn_nhwc_stats, dim3(B * p.nchunk), block, stats_lds, st, p);
     if (!p.inline_stats) DSC_LAUNCH(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
+    if (p.x2) { p.x = p.cat; p.x2 = nullptr; }                  // the statistics pass wrote the concatenation: apply streams it
     DSC_LAUNCH(gn_nhwc_apply, dim3(B * p.anchunk), block, 0, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
+}  // namespace

@@ -320,6 +320,13 @@ class GroupNormAct(nn.GroupNorm):
     def forward(self, x, add=None):
         return ops.groupnorm_silu_nhwc(x, self.num_groups, self.weight, self.bias, self.eps, self.act, add=add)
 
+    def of_cat(self, x1, x2):
+        """(norm(cat([x1, x2], 1)), cat([x1, x2], 1)): the concatenation is a by-product of the statistics pass"""
+        if ops.groupnorm_cat_covers(x1, x2):
+            return ops.groupnorm_silu_nhwc_cat(x1, x2, self.num_groups, self.weight, self.bias, self.eps, self.act)
+        x = torch.cat([x1, x2], dim=1)
+        return self.forward(x), x
+
 
 class Attention(nn.Module):
     """The module the processors receive as `attn` (attributes listed in SURVEY.md 8b)."""
@@ -530,7 +537,11 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb_act, temb_add=None):
         # conv biases never run as separate MIOpen bias kernels: conv1's is folded into the time-embedding term (which
         # is itself folded into norm2's load), conv2's into the shortcut GEMM's bias or the fused residual add
-        h = _conv3x3(self.norm1(x), self.conv1.weight)
+        if isinstance(x, tuple):            # up blocks: (hidden_states, skip) - norm1 produces their concatenation
+            h, x = self.norm1.of_cat(*x)
+        else:
+            h = self.norm1(x)
+        h = _conv3x3(h, self.conv1.weight)
         if temb_add is None:
             temb_add = F.linear(temb_act, self.time_emb_proj.weight, self.temb_bias())
         if self.conv_shortcut is None:
@@ -804,7 +815,7 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
             x = x + mid_block_additional_residual
         for blk in self.up_blocks:
             for j, res in enumerate(blk.resnets):
-                x = res(torch.cat([x, skips.pop()], dim=1), temb_act, tadd[res])
+                x = res((x, skips.pop()), temb_act, tadd[res])
                 if blk.has_attn:
                     x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
             if hasattr(blk, "upsamplers"):

@@ -271,6 +271,42 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
     return y
 
 
+USE_GN_CAT = os.environ.get("DSC_GN_CAT", "1") != "0"   # up blocks: the skip concatenation is written by the GroupNorm that reads it
+
+
+def groupnorm_cat_covers(x1, x2):
+    """True when dsc_groupnorm_silu_nhwc_cat takes this pair of channels_last [B, C1, h, w] / [B, C2, h, w] tensors"""
+    cl = torch.channels_last
+    return (USE_GN_CAT and x1.is_cuda and x1.dtype == torch.float16 and x2.dtype == torch.float16 and x1.dim() == 4
+            and x2.dim() == 4 and x1.shape[0] == x2.shape[0] and x1.shape[2:] == x2.shape[2:] and x1.shape[1] % 8 == 0
+            and x2.shape[1] % 8 == 0 and (x1.shape[1] + x2.shape[1]) // 8 <= 512
+            and x1.is_contiguous(memory_format=cl) and x2.is_contiguous(memory_format=cl))
+
+
+def groupnorm_silu_nhwc_cat(x1, x2, groups, weight, bias, eps, act, add=None):
+    """(GroupNorm [+ SiLU] of cat([x1, x2], dim=1), the concatenation itself), both channels_last: the statistics pass reads
+    the two sources and writes the concatenation on the way (dsc_groupnorm_silu_nhwc_cat) - no separate cat kernel."""
+    _require_gpu(x1, x2)
+    if not groupnorm_cat_covers(x1, x2):
+        raise ValueError("groupnorm_silu_nhwc_cat: channels_last fp16 [B, C, h, w] pairs with C % 8 == 0 only")
+    lib = _lib.load_library()
+    B, C1, h, w = x1.shape
+    C = C1 + x2.shape[1]
+    cat = torch.empty((B, C, h, w), dtype=x1.dtype, device=x1.device, memory_format=torch.channels_last)
+    y = torch.empty_like(cat, memory_format=torch.channels_last)
+    add_stride = 0
+    if add is not None:
+        if add.stride(-1) != 1 or add.stride(0) % 8 != 0 or add.data_ptr() % 16 != 0:
+            add = add.contiguous()
+        add_stride = add.stride(0)
+    ws = _workspace(x1.device, lib.dsc_groupnorm_nhwc_workspace_bytes(B, C, h * w, groups))
+    rc = lib.dsc_groupnorm_silu_nhwc_cat(_p(x1), _p(x2), C1, _p(cat), _p(y), _p(weight), _p(bias), _p(add), add_stride, B, C,
+                                         h * w, groups, float(eps), 1 if act else 0, 0, _p(ws), ws.numel() * 8,
+                                         _stream_ptr(x1))
+    _lib.check(rc, "dsc_groupnorm_silu_nhwc_cat")
+    return y, cat
+
+
 USE_LT_RESIDUAL = os.environ.get("DSC_LT_RESIDUAL", "1") != "0"   # GEMMs left to hipBLASLt take bias + residual in the same launch (dsc_linear_lt_f16)
 USE_LT_ALL = os.environ.get("DSC_LT_ALL", "1") != "0"   # ... and the ones without a residual go the same way (measured algorithm choice, DSC_LT_TUNE)
 USE_DSC_GEMM = True        # route qualifying linears to dsc_linear_f16 (False: always hipBLASLt through torch)

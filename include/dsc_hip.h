@@ -199,6 +199,16 @@ int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const voi
                             const void* add, int64_t add_row_stride,   /* elements between rows of `add` (>= C) */
                             int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same over the channel concatenation [x1 | x2] that the caller never materialised - the up blocks'
+ * `torch.cat([hidden_states, res_hidden_states], dim=1)` in front of every ResNet block (diffusers UpBlock2D /
+ * CrossAttnUpBlock2D, reached from reference u_net_condition_modify.py:1274-1302): x1 [B, hw, C1], x2 [B, hw, C - C1],
+ * C1 % 8 == 0.  The pass that reads the two sources for the statistics also writes the concatenation to `cat`
+ * [B, hw, C] (the block's 1x1 shortcut reads it), so the separate concatenation kernel and one read of the tensor go away.
+ * y as above.  cat must not alias x1, x2 or y.  Same workspace as dsc_groupnorm_silu_nhwc for (B, C, hw, groups). */
+int dsc_groupnorm_silu_nhwc_cat(const void* x1, const void* x2, int C1, void* cat, void* y, const void* gamma,
+                                const void* beta, const void* add, int64_t add_row_stride, int B, int C, int hw,
+                                int groups, float eps, int apply_silu, int dtype, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* out[r, c] = a[r, c] + b[r, c] + bias[c] over fp16 [rows, C] (channels-last residual add with the convolution's
  * bias folded in: the ResNet block's `x + conv2(h)` where conv2 ran without its bias).  bias may be NULL. C % 8 == 0. */

@@ -68,6 +68,39 @@ def test_groupnorm_silu_nhwc(ops, B, C, h, w, G, act, with_add):
     assert torch.equal(y2.reshape(B, h, w, C).permute(0, 3, 1, 2), y)
 
 
+@pytest.mark.parametrize("B,C1,C2,h,w,G,act", [(2, 1280, 1280, 8, 8, 32, True),      # single-launch kernel
+                                                (2, 1280, 1280, 16, 16, 32, True), (2, 1280, 640, 16, 16, 32, True),
+                                                (2, 1280, 640, 32, 32, 32, True), (2, 640, 320, 32, 32, 32, True),
+                                                (2, 640, 320, 64, 64, 32, True), (2, 320, 320, 64, 64, 32, True),   # finalize launch
+                                                (16, 320, 320, 64, 64, 32, True), (3, 40, 24, 5, 7, 8, False),
+                                                (1, 8, 56, 3, 3, 4, True), (2, 1280, 1280, 12, 12, 32, True)])
+def test_groupnorm_of_concatenation(ops, B, C1, C2, h, w, G, act):
+    """dsc_groupnorm_silu_nhwc_cat: GroupNorm over [x1 | x2] with the concatenation as a by-product of the statistics pass.
+    Same arithmetic as the plain kernel on the materialised concatenation -> bit-equal; the concatenation is a byte copy."""
+    g = torch.Generator().manual_seed(C1 + C2 + h)
+    cl = torch.channels_last
+    x1 = (torch.randn(B, C1, h, w, generator=g) * 1.3 + 0.2).half().cuda().contiguous(memory_format=cl)
+    x2 = (torch.randn(B, C2, h, w, generator=g) * 0.7 - 0.4).half().cuda().contiguous(memory_format=cl)
+    gamma = (torch.randn(C1 + C2, generator=g) * 0.5 + 1).half().cuda()
+    beta = (torch.randn(C1 + C2, generator=g) * 0.3).half().cuda()
+    assert ops.groupnorm_cat_covers(x1, x2)
+    y, cat = ops.groupnorm_silu_nhwc_cat(x1, x2, G, gamma, beta, 1e-5, act)
+    want_cat = torch.cat([x1, x2], dim=1).contiguous(memory_format=cl)
+    assert cat.is_contiguous(memory_format=cl) and torch.equal(cat, want_cat)
+    assert torch.equal(y, ops.groupnorm_silu_nhwc(want_cat, G, gamma, beta, 1e-5, act))
+    ref = F.group_norm(want_cat.float(), G, gamma.float(), beta.float(), 1e-5)
+    ref = F.silu(ref) if act else ref
+    assert (y.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_groupnorm_of_concatenation_rejects(ops):
+    x1 = torch.randn(1, 12, 4, 4).half().cuda().contiguous(memory_format=torch.channels_last)      # 12 % 8 != 0
+    x2 = torch.randn(1, 20, 4, 4).half().cuda().contiguous(memory_format=torch.channels_last)
+    assert not ops.groupnorm_cat_covers(x1, x2)
+    with pytest.raises(ValueError):
+        ops.groupnorm_silu_nhwc_cat(x1, x2, 4, torch.ones(32).half().cuda(), torch.zeros(32).half().cuda(), 1e-5, True)
+
+
 @pytest.mark.parametrize("B,H,L,d", [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160),
                                      (1, 4, 100, 64), (2, 10, 576, 64), (3, 5, 33, 16), (2, 8, 144, 160), (1, 2, 2304, 40),
                                      (2, 20, 1024, 64), (1, 1, 1, 8)])
