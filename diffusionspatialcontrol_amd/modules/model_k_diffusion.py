@@ -250,13 +250,32 @@ class StableDiffusionPipeline:
         named = {"karras": sampling.get_sigmas_karras, "exponential": sampling.get_sigmas_exponential,
                  "polyexponential": sampling.get_sigmas_polyexponential}
         if params.get("scheduler", None) in named:
-            smin, smax = self.k_diffusion_model.sigmas[0].item(), self.k_diffusion_model.sigmas[-1].item()
-            sigmas = named[params["scheduler"]](n=steps, sigma_min=smin, sigma_max=smax, device=self.device)
+            # sigma_min / sigma_max are constants of the model: read once (a device->host copy synchronises, and a
+            # synchronisation per generation keeps the host from preparing generation i+1 under generation i's replays);
+            # the 26-entry schedule is computed on the host
+            kdm = self.k_diffusion_model
+            rng = getattr(self, "_sigma_range", None)
+            if rng is None or rng[0] is not kdm:
+                rng = self._sigma_range = (kdm, kdm.sigmas[0].item(), kdm.sigmas[-1].item())
+            sigmas = named[params["scheduler"]](n=steps, sigma_min=rng[1], sigma_max=rng[2], device="cpu")
         else:
             sigmas = self.k_diffusion_model.get_sigmas(steps)
         if discard:
             sigmas = torch.cat([sigmas[:-2], sigmas[-1:]])
         return sigmas
+
+    def _schedule(self, steps, params, device, dtype):
+        """get_sigmas() cast to the model dtype on the device (reference :1027-1029: fp16 rounding is part of the schedule).
+        A host-computed schedule is rounded on the host (round-to-nearest-even, as the device cast), uploaded from pinned
+        memory without blocking, and carries the rounded values as host floats (`_dsc_host`) for the fused loop."""
+        s = self.get_sigmas(steps, params)
+        device = torch.device(device)
+        if s.is_cuda or device.type != "cuda":
+            return s.to(device, dtype=dtype)
+        h = s.to(dtype=dtype)
+        d = h.pin_memory().to(device, non_blocking=True)
+        d._dsc_host = h.float().tolist()
+        return d
 
     def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
         shape = (batch_size, num_channels_latents, height // 8, width // 8)
@@ -463,7 +482,7 @@ class StableDiffusionPipeline:
             text = torch.cat([negative_prompt_embeds.repeat_interleave(num_images_per_prompt, dim=0), text])   # :1021
         text = text.to(device=device, dtype=self.unet.dtype)
         # sigmas are cast to the model dtype on the device (:1027-1029): fp16 rounding is part of the schedule
-        sigmas = self.get_sigmas(num_inference_steps, sampler_opt).to(device, dtype=text.dtype)
+        sigmas = self._schedule(num_inference_steps, sampler_opt, device, text.dtype)
         latents = self.prepare_latents(n_img, self.unet.config.in_channels, height, width, text.dtype, device,
                                        generator, latents)
         latents = latents * (sigmas[0] ** 2 + 1) ** 0.5                                                      # :1043
@@ -669,7 +688,7 @@ class StableDiffusionPipeline:
             latents = latents.repeat(n_img // latents.shape[0], 1, 1, 1)
         init_timestep = min(int(num_inference_steps * strength), num_inference_steps)                # :637-638
         t_start = max(num_inference_steps - init_timestep, 0)
-        sigmas = self.get_sigmas(num_inference_steps, sampler_opt).to(device, dtype=text.dtype)
+        sigmas = self._schedule(num_inference_steps, sampler_opt, device, text.dtype)
         sigma_sched = sigmas[t_start:]
         noise = self._randn_like_ref(latents.shape, generator, device, text.dtype)
         latents = latents + noise * (sigma_sched[0] ** 2 + 1) ** 0.5                                 # :647
@@ -782,7 +801,7 @@ class StableDiffusionPipeline:
                                                              device)
         init_timestep = min(int(num_inference_steps * strength), num_inference_steps)                # :1432-1438
         t_start = max(num_inference_steps - init_timestep, 0)
-        sigmas = self.get_sigmas(num_inference_steps, sampler_opt).to(device, dtype=text.dtype)
+        sigmas = self._schedule(num_inference_steps, sampler_opt, device, text.dtype)
         sigmas = sigmas[t_start:] if 0 <= strength < 1.0 else sigmas
         is_strength_max = strength == 1.0
         init_image = self._image_tensor(image, height, width) if not (isinstance(image, torch.Tensor) and image.shape[1] == 4) \
@@ -1063,8 +1082,9 @@ class StableDiffusionPipeline:
             return
         for L, (ids, rws) in comp_cpu.items():
             dst_ids, dst_rows = st["compressed"][L]
-            dst_ids.copy_(ids, non_blocking=True)
-            dst_rows.copy_(rws, non_blocking=True)
+            # pinned staging: a copy from pageable memory waits for the stream, i.e. for the previous generation
+            dst_ids.copy_(ids.pin_memory() if dst_ids.is_cuda else ids, non_blocking=True)
+            dst_rows.copy_(rws.pin_memory() if dst_rows.is_cuda else rws, non_blocking=True)
 
     def _refresh_text_kv(self, text):
         """K/V projections of the text for every cross-attention layer, once per generation (they are step-invariant;
@@ -1103,7 +1123,9 @@ class StableDiffusionPipeline:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         kdm = self.k_diffusion_model
-        sig = sigmas.detach().float().cpu().tolist()                 # the only device->host transfer, before the loop
+        sig = getattr(sigmas, "_dsc_host", None)                     # host copy made where the schedule was built, or
+        if sig is None:
+            sig = sigmas.detach().float().cpu().tolist()             # one device->host transfer before the loop
         coeffs = sampling.dpmpp_2m_coefficients(sig)
         levels = tuple(sorted((int(L), tuple(w.shape)) for L, w in region_state.items())) \
             if isinstance(region_state, dict) else None
