@@ -180,6 +180,28 @@ def test_product_path_fails_loudly_without_gpu():
                      output_type="latent", fused=False)
 
 
+def test_schedule_is_built_on_the_host_and_cached():
+    """get_sigmas: sigma_min / sigma_max read from the denoiser once (a device read would synchronise every generation),
+    the schedule computed on the host; _schedule: the model-dtype cast of it (reference model_k_diffusion.py:1027-1029)"""
+    unet = UNet2DConditionModel(UNetConfig.tiny()).half()
+    pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+    kdm = pipe.k_diffusion_model
+    for name in ("karras", "exponential", "polyexponential"):
+        s = pipe.get_sigmas(12, {"scheduler": name})
+        assert s.device.type == "cpu" and s.shape == (13,) and float(s[-1]) == 0.0
+    assert pipe._sigma_range[0] is kdm and pipe._sigma_range[1] == kdm.sigmas[0].item() and pipe._sigma_range[2] == kdm.sigmas[-1].item()
+    want = sampling.get_sigmas_karras(12, kdm.sigmas[0].item(), kdm.sigmas[-1].item())
+    assert torch.equal(pipe.get_sigmas(12, {"scheduler": "karras"}), want)
+    assert torch.equal(pipe.get_sigmas(12, {"scheduler": "karras", "discard_next_to_last_sigma": True}),
+                       torch.cat([sampling.get_sigmas_karras(13, kdm.sigmas[0].item(), kdm.sigmas[-1].item())[:-2], want[-1:]]))
+    d = pipe._schedule(12, {"scheduler": "karras"}, "cpu", torch.float16)
+    assert d.dtype == torch.float16 and torch.equal(d, want.half())
+    assert torch.equal(pipe.get_sigmas(12, {}), kdm.get_sigmas(12))          # the model's own discrete schedule otherwise
+    pipe.k_diffusion_model = ek.CompVisDenoiser(pipe.k_diffusion_model.inner_model, quantize=False)    # a new denoiser: re-read
+    pipe.get_sigmas(5, {"scheduler": "karras"})
+    assert pipe._sigma_range[0] is pipe.k_diffusion_model
+
+
 def test_vae_decoder_structure():
     """SD1.x AutoencoderKL decoder half: 49,490,199 parameters (decoder 49,490,179 + post_quant_conv 20), diffusers keys"""
     from diffusionspatialcontrol_amd.modules.vae_decoder import AutoencoderKLDecoder
