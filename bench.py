@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--deterministic-conv", action="store_true",
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
                          "falls back to kernels >10x slower on this image; off by default")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="generations in flight per GPU: N host threads, each with its own stream and generation slot (static "
+                         "buffers, captured step, packed K/V, library workspace); every generation is still one batch-1 image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-roofline", action="store_true",
                     help="skip roofline_at_8_images (profiling runs: its Bc = 16 launches of the same kernels would mix into the "
@@ -280,24 +283,57 @@ def main():
     lat = torch.stack([torch.randn(4, a.size // 8, a.size // 8, generator=torch.Generator().manual_seed(1000 + i))
                        for i in my_images]).half().to(dev)
 
-    def generate():
+    def generate(slot=0):
         out = pipe.txt2img(None, height=a.size, width=a.size, num_inference_steps=a.denoise_steps, guidance_scale=7.5,
                            latents=lat, output_type="latent", region_map_state=state, sampler_name="sample_dpmpp_2m",
                            sampler_opt={"scheduler": "karras"}, prompt_embeds=emb[1:2], negative_prompt_embeds=emb[0:1],
-                           text_input_ids=ids, num_images_per_prompt=n_img)[0]
+                           text_input_ids=ids, num_images_per_prompt=n_img, slot=slot)[0]
         if a.decode:                                         # pixels stay on the device (decode_latents' .cpu() is host I/O)
             out = (vae.decode(out / vae.config.scaling_factor).sample / 2 + 0.5).clamp(0, 1)
         return out
 
     out = None
-    for _ in range(a.warmup):
-        out = generate()
+    nfl = max(1, a.in_flight)
+    streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else None
+    if nfl > 1:
+        if a.decode:
+            raise SystemExit("--in-flight > 1 times the denoising loop only")
+        torch.cuda.synchronize()
+        for s_i, st in enumerate(streams):                  # captures and algorithm timing happen here, one slot at a time
+            with torch.cuda.stream(st):
+                for _ in range(max(1, a.warmup)):
+                    out = generate(s_i)
+            torch.cuda.synchronize()
+    else:
+        for _ in range(a.warmup):
+            out = generate()
     if dist:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = generate()
+    if nfl > 1:
+        import threading
+        outs, errs = [None] * nfl, []
+
+        def drive(s_i):
+            try:
+                with torch.cuda.stream(streams[s_i]):
+                    for _ in range(s_i, a.steps, nfl):      # generations s_i, s_i + nfl, ...: a.steps in total
+                        outs[s_i] = generate(s_i)
+            except BaseException as e:                      # noqa: BLE001 - re-raised on the main thread
+                errs.append(e)
+
+        threads = [threading.Thread(target=drive, args=(i,)) for i in range(nfl)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+        out = next(o for o in reversed(outs) if o is not None)
+    else:
+        for _ in range(a.steps):
+            out = generate()
     torch.cuda.synchronize()
     if dist:
         td.barrier()
@@ -318,6 +354,7 @@ def main():
             "config": {"workload": f"SD1.5 {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
                                    f"{a.regions} region masks, {n_img} image(s) per GPU per generation",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
+                       "generations_in_flight": nfl,
                        "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite, "vae_decode_in_timed_region": bool(a.decode)},
         }
         res["roofline"] = roofline_region_xattn(dev, n_img)

@@ -43,9 +43,17 @@ struct Plan {
 };
 
 hipblasLtHandle_t g_handle = nullptr;
-void* g_ws = nullptr;
+// One workspace per generation slot (stream-K kernels keep partial tiles there): the GEMMs of two generations in flight on two
+// streams - issued eagerly or baked into two captured graphs - must not share one.  The host thread that drives a slot
+// names it with dsc_set_workspace_slot(); the pool is allocated up front because a first call may come from inside a
+// stream capture, where hipMalloc is not allowed.
 constexpr size_t kWsBytes = 32u << 20;
+constexpr int kWsPool = 4;
+void* g_ws_pool[kWsPool] = {};
+thread_local int t_ws_slot = 0;
 std::mutex g_mu;
+
+void* workspace_for() { return g_ws_pool[t_ws_slot]; }
 std::map<std::tuple<int64_t, int, int, int64_t, int64_t, int64_t, int, int>, Plan> g_plans;
 
 bool build_plan(Plan& p, int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, bool bias, bool res) {
@@ -91,6 +99,7 @@ constexpr size_t kFlushBytes = 512u << 20;
 
 void tune_plan(Plan& p, const void* x, const void* w, const void* residual, void* out, int64_t M, int K, int64_t ldx,
                hipStream_t stream) {
+    void* const g_ws = workspace_for();
     p.tuned = true;
     if (p.n_cand < 2 || residual == out) return;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -132,6 +141,12 @@ void tune_plan(Plan& p, const void* x, const void* w, const void* residual, void
 
 }  // namespace
 
+extern "C" int dsc_set_workspace_slot(int slot) {
+    if (slot < 0 || slot >= kWsPool) return DSC_ERR_BAD_ARG;
+    t_ws_slot = slot;
+    return DSC_OK;
+}
+
 // Not capturable on its FIRST call for a shape (handle / workspace allocation, heuristic query): the pipeline's warm-up
 // steps run it outside the graph capture, exactly like torch's own hipBLASLt path.
 extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -139,34 +154,32 @@ extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias,
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16 || K % 8 != 0 || N % 8 != 0 || ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0))
         return DSC_ERR_UNSUPPORTED;
-    Plan* plan = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_handle) {
-            if (hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return DSC_ERR_LAUNCH;
-            if (hipMalloc(&g_ws, kWsBytes) != hipSuccess) return DSC_ERR_WORKSPACE;
+    // one lock around lookup, bias pointer and launch: the descriptor of a shape is shared, and two host threads (two
+    // generations in flight) issue the same shapes with different bias pointers
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_handle) {
+        if (hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) return DSC_ERR_LAUNCH;
+        for (int i = 0; i < kWsPool; ++i) {
+            // zeroed once: the stream-K kernels keep arrival flags there that they reset themselves after use
+            if (hipMalloc(&g_ws_pool[i], kWsBytes) != hipSuccess || hipMemset(g_ws_pool[i], 0, kWsBytes) != hipSuccess)
+                return DSC_ERR_WORKSPACE;
         }
-        const auto key = std::make_tuple(M, N, K, ldx, residual ? ldr : (int64_t)0, ldo, bias ? 1 : 0, residual ? 1 : 0);
-        auto it = g_plans.find(key);
-        if (it == g_plans.end()) {
-            Plan p;
-            build_plan(p, M, N, K, ldx, ldr, ldo, bias != nullptr, residual != nullptr);
-            it = g_plans.emplace(key, p).first;
-        }
-        plan = &it->second;
     }
+    const auto key = std::make_tuple(M, N, K, ldx, residual ? ldr : (int64_t)0, ldo, bias ? 1 : 0, residual ? 1 : 0);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        Plan p;
+        build_plan(p, M, N, K, ldx, ldr, ldo, bias != nullptr, residual != nullptr);
+        it = g_plans.emplace(key, p).first;
+    }
+    Plan* plan = &it->second;
     if (!plan->ok) return DSC_ERR_UNSUPPORTED;
-    if (bias) {
-        // the descriptor is shared by every call of this shape: set the pointer right before the launch (single-stream use)
-        hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
-    }
-    if (!plan->tuned) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!plan->tuned) tune_plan(*plan, x, w, residual, out, M, K, ldx, static_cast<hipStream_t>(stream));
-    }
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (bias) hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    if (!plan->tuned) tune_plan(*plan, x, w, residual, out, M, K, ldx, hs);
     const float alpha = 1.f, beta = residual ? 1.f : 0.f;
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta,
-                                               residual ? residual : out, plan->c, out, plan->d, &plan->algo, g_ws, kWsBytes,
-                                               static_cast<hipStream_t>(stream));
+                                               residual ? residual : out, plan->c, out, plan->d, &plan->algo,
+                                               workspace_for(), kWsBytes, hs);
     return st == HIPBLAS_STATUS_SUCCESS ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -271,6 +271,8 @@ class _RegionProcessor:
             elif attn.norm_cross:
                 encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
             cache = getattr(attn, "kv_cache", None)
+            if cache is not None and cache["src"] is not encoder_hidden_states:     # another generation slot's text buffer?
+                cache = next((c for c in getattr(attn, "kv_caches", ()) if c["src"] is encoder_hidden_states), None)
             if cache is not None and cache["src"] is encoder_hidden_states:
                 key, value = cache["k"], cache["v"]          # text K/V: once per generation, not once per step
                 packed_kv = cache.get("packed")

@@ -33,7 +33,7 @@ from typing import List, Optional, Union
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from . import sampling
 from .encode_region_map_function import encode_region_map
 from .external_k_diffusion import CompVisDenoiser, CompVisVDenoiser
@@ -444,7 +444,7 @@ class StableDiffusionPipeline:
                 ip_adapter_image_embeds=None,
                 # build-specific inputs (the prompt encoders are a "next" row):
                 prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
-                text_input_ids=None, fused: Optional[bool] = None, **unsupported):
+                text_input_ids=None, fused: Optional[bool] = None, slot: int = 0, **unsupported):
         hires = dict(prompt=prompt, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
                      negative_prompt=negative_prompt, generator=generator, strength=upscale_denoising_strength,
                      sampler_name=sampler_name_hires or sampler_name, sampler_opt=sampler_opt_hires or sampler_opt,
@@ -514,8 +514,10 @@ class StableDiffusionPipeline:
             if control_hook is not None or preview is not None:
                 raise NotImplementedError("ControlNet / T2I-Adapter / latent previews run in protocol mode (fused=False)")
             latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
-                                          cross_attention_kwargs, start_time, timeout)
+                                          cross_attention_kwargs, start_time, timeout, slot=slot)
         else:
+            if slot:
+                raise NotImplementedError("generation slots (two generations in flight) exist for the fused DPM++ 2M loop only")
             latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                              guidance_rescale, n_img, cross_attention_kwargs, eta,
                                              num_inference_steps, sampler_opt, seed, start_time, timeout,
@@ -1003,6 +1005,9 @@ class StableDiffusionPipeline:
         comp_cpu = self._compress_tables(region_state)
         ack = self._added_cond_kwargs
         if st is not None and (st["compressed"] is None) == (comp_cpu is None):
+            done = st.get("done")
+            if done is not None:         # the slot's buffers may last have been driven from another stream
+                torch.cuda.current_stream(text.device).wait_event(done)
             if ack is not None:
                 for dst, src in zip(st["image_embeds"], ack["image_embeds"]):
                     dst.copy_(src)
@@ -1059,8 +1064,15 @@ class StableDiffusionPipeline:
                 st["eps"] = step()
             st["graph"] = g
             st["run"] = g.replay
-        self._graphs = {key: st}                 # keep one
+        # keep one captured step per generation slot
+        tag = self._slot_of(key)
+        self._graphs = {k: v for k, v in self._graphs.items() if self._slot_of(k) != tag}
+        self._graphs[key] = st
         return st
+
+    @staticmethod
+    def _slot_of(key):
+        return key[0][1] if isinstance(key[0], tuple) and key[0][:1] == ("slot",) else 0
 
     @staticmethod
     def _compress_tables(region_state):
@@ -1096,12 +1108,16 @@ class StableDiffusionPipeline:
                 k, v = m.to_k(text), m.to_v(text)
                 B, S, C = k.shape
                 d = C // m.heads
-                c = m.kv_cache
-                if c is not None and c["src"] is text and c["k"].shape == k.shape:
+                # one entry per static text buffer (= per generation slot); the newest few are kept
+                slots = m.__dict__.setdefault("kv_caches", [])
+                c = next((e for e in slots if e["src"] is text and e["k"].shape == k.shape), None)
+                if c is not None:
                     c["k"].copy_(k)
                     c["v"].copy_(v)
                 else:
-                    c = m.kv_cache = {"src": text, "k": k, "v": v, "packed": None}
+                    c = {"src": text, "k": k, "v": v, "packed": None}
+                    slots[:] = [e for e in slots if e["src"] is not text][-3:] + [c]
+                m.kv_cache = c
                 # MFMA-fragment image of K / V^T for the fused kernel (rewritten in place: captured graphs keep reading it)
                 if S <= 384 and d % 8 == 0 and d <= 160:          # > 96 keys: one image per 96-key chunk (long prompts)
                     c["packed"] = ops.xattn_kv_pack(c["k"].view(B, S, m.heads, d), c["v"].view(B, S, m.heads, d),
@@ -1112,9 +1128,10 @@ class StableDiffusionPipeline:
         for m in self.unet.modules():
             if isinstance(m, Attention):
                 m.kv_cache = None
+                m.__dict__.pop("kv_caches", None)
 
     def _denoise_fused(self, latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
-                       cross_attention_kwargs, start_time, timeout):
+                       cross_attention_kwargs, start_time, timeout, slot=0):
         if self.v_prediction:
             raise NotImplementedError("the fused step (dsc_cfg_dpmpp2m_step) computes denoised = x - sigma * eps; "
                                       "v-prediction models run in protocol mode (fused=False)")
@@ -1132,8 +1149,12 @@ class StableDiffusionPipeline:
         ack = getattr(self, "_added_cond_kwargs", None)
         ip_key = None if ack is None else (tuple(tuple(e.shape) for e in ack["image_embeds"]),
                                            id(getattr(self.unet, "encoder_hid_proj", None)))
-        key = (n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
+        key = (("slot", slot), n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
                if hasattr(weight_func, "__code__") else id(weight_func), ip_key)
+        if latents.is_cuda:
+            # generation slots: each keeps its own static buffers, captured step, packed K/V and library-GEMM workspace, so
+            # two generations can be in flight on two streams (one host thread per slot)
+            _lib.check(_lib.load_library().dsc_set_workspace_slot(slot), "dsc_set_workspace_slot")
         st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs)
         x = latents.contiguous().clone()
         old = torch.zeros_like(x)
@@ -1151,6 +1172,11 @@ class StableDiffusionPipeline:
             # x <- a*x + b*D + c*D_old with D = x - sigma*(eps_u + g*(eps_c - eps_u)); also writes next x_in/t/sigma
             ops.cfg_dpmpp2m_step(x, st["eps"], old, sig[i], guidance_scale, a, b, c, c_in_n, t_n, max(nxt, 1e-10),
                                  st["x_in"], st["t"], st["sigma"])
+        if x.is_cuda:
+            done = st.get("done")
+            if done is None:
+                done = st["done"] = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(x.device))
         if prof:
             torch.cuda.synchronize()
             t2 = time.perf_counter()

@@ -295,6 +295,11 @@ int dsc_conv3x3_fewcin_f16(const void* x_nchw, const void* w_t, const void* bias
  */
 int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                       int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int dtype, void* stream);
+/* Generation slot of the calling host thread (0..3, default 0): which of the library-GEMM workspaces dsc_linear_lt_f16 hands
+ * to hipBLASLt (its stream-K kernels keep partial tiles there).  A pipeline that keeps two generations in flight on two
+ * streams drives each from its own thread / slot, so that neither the eager GEMMs nor the ones baked into the two captured
+ * step graphs share a workspace.  Thread-local; returns DSC_ERR_BAD_ARG outside 0..3. */
+int dsc_set_workspace_slot(int slot);
 
 /*
  * Few-row linear (M <= 8) for the time-embedding path: y[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) - `Timesteps` +
