@@ -42,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3, help="timed generations (each = 25 denoising steps)")
+    ap.add_argument("--steps", type=int, default=6, help="timed generations (each = 25 denoising steps)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--size", type=int, default=512)
@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--deterministic-conv", action="store_true",
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
                          "falls back to kernels >10x slower on this image; off by default")
-    ap.add_argument("--in-flight", type=int, default=1,
+    ap.add_argument("--in-flight", type=int, default=2,
                     help="generations in flight per GPU: N host threads, each with its own stream and generation slot (static "
                          "buffers, captured step, packed K/V, library workspace); every generation is still one batch-1 image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -293,11 +293,9 @@ def main():
         return out
 
     out = None
-    nfl = max(1, a.in_flight)
+    nfl = 1 if (a.decode or a.no_graph) else max(1, a.in_flight)     # slots exist for the captured denoising loop
     streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else None
     if nfl > 1:
-        if a.decode:
-            raise SystemExit("--in-flight > 1 times the denoising loop only")
         torch.cuda.synchronize()
         for s_i, st in enumerate(streams):                  # captures and algorithm timing happen here, one slot at a time
             with torch.cuda.stream(st):
@@ -315,10 +313,15 @@ def main():
         import threading
         outs, errs = [None] * nfl, []
 
+        todo, todo_lock = iter(range(a.steps)), threading.Lock()
+
         def drive(s_i):
             try:
                 with torch.cuda.stream(streams[s_i]):
-                    for _ in range(s_i, a.steps, nfl):      # generations s_i, s_i + nfl, ...: a.steps in total
+                    while True:                             # a.steps generations in total, whichever slot is free next
+                        with todo_lock:
+                            if next(todo, None) is None:
+                                break
                         outs[s_i] = generate(s_i)
             except BaseException as e:                      # noqa: BLE001 - re-raised on the main thread
                 errs.append(e)
@@ -343,6 +346,23 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = tt.item()
     finite = bool(torch.isfinite(out).all().item())
+    dt_seq = None
+    if nfl > 1:                                             # the same K generations one after the other (slot 0), for reference
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            for _ in range(a.steps):
+                out = generate(0)
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+        dt_seq = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([dt_seq], device=dev, dtype=torch.float64)
+            td.all_reduce(tt, op=td.ReduceOp.MAX)
+            dt_seq = tt.item()
 
     if rank == 0:
         images = n_img * world * a.steps
@@ -352,11 +372,16 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SD1.5 {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
-                                   f"{a.regions} region masks, {n_img} image(s) per GPU per generation",
+                                   f"{a.regions} region masks, {n_img} image(s) per generation, "
+                                   f"{nfl} generation(s) in flight per GPU",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
-                       "generations_in_flight": nfl,
+                       "generations_in_flight": nfl, "images_per_generation": n_img,
                        "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite, "vae_decode_in_timed_region": bool(a.decode)},
         }
+        if dt_seq is not None:
+            res["one_generation_at_a_time"] = {"value": round(images / dt_seq, 4), "unit": "images/s",
+                                               "ms_per_generation": round(dt_seq / a.steps * 1e3, 2),
+                                               "note": "the same K generations with one in flight (latency of one image)"}
         res["roofline"] = roofline_region_xattn(dev, n_img)
         res["roofline_self_attn"] = roofline_self_attn(dev, n_img)
         res["roofline_conv3x3"] = roofline_conv3x3(dev, n_img)
