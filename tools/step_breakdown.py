@@ -1,7 +1,7 @@
 """Steady-state breakdown of one UNet step from a rocprofv3 kernel trace of bench.py.
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof -- python bench.py --steps 6 --warmup 2 \\
-        --no-cpu-baseline --no-batched-roofline
+        --no-cpu-baseline --no-batched-roofline --in-flight 1
     python tools/step_breakdown.py gpurun_out/prof/*/*_kernel_trace.csv
 
 The fused sampler kernel (`step_kernel`, one per step) delimits the steps; the last 20 steps of the run are averaged,
