@@ -317,6 +317,7 @@ def main():
 
         def drive(s_i):
             try:
+                torch.cuda.set_device(dev)                  # the current device is per host thread
                 with torch.cuda.stream(streams[s_i]):
                     while True:                             # a.steps generations in total, whichever slot is free next
                         with todo_lock:
