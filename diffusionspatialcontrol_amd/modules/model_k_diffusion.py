@@ -28,6 +28,7 @@ external_k_diffusion.py:109-114 broadcasts c_in[B] against input[2B]).
 import importlib
 import inspect
 import os
+import threading
 import time
 from typing import List, Optional, Union
 
@@ -68,6 +69,9 @@ def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
     dims = list(range(1, noise_pred_text.ndim))
     factor = noise_pred_text.std(dim=dims, keepdim=True) / noise_cfg.std(dim=dims, keepdim=True)
     return guidance_rescale * (noise_cfg * factor) + (1 - guidance_rescale) * noise_cfg
+
+
+_CAPTURE_LOCK = threading.RLock()
 
 
 class StableDiffusionPipeline:
@@ -996,8 +1000,17 @@ class StableDiffusionPipeline:
                         dst.copy_(src)
         return out
 
-    def _static_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs, control=None,
-                     n_std_groups=None):
+    def _static_step(self, key, *args, **kwargs):
+        """_build_or_refresh_step, with first-time creation (warm-up launches + stream capture) serialised across host
+        threads: a capture must not overlap another thread's allocations.  Generation slots should still be created one
+        after the other before they run concurrently - a running slot's thread allocates too."""
+        if key in self._graphs:
+            return self._build_or_refresh_step(key, *args, **kwargs)
+        with _CAPTURE_LOCK:
+            return self._build_or_refresh_step(key, *args, **kwargs)
+
+    def _build_or_refresh_step(self, key, n_img, lat_shape, text, region_state, weight_func, cross_attention_kwargs, control=None,
+                               n_std_groups=None):
         """Static buffers + the captured UNet step.  The graph is keyed by SHAPES only: a new generation with other
         text / other region masks updates the static buffers in place (text, its packed K/V, the compressed region
         tables) and replays the same graph."""
