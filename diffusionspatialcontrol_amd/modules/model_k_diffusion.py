@@ -520,12 +520,10 @@ class StableDiffusionPipeline:
             latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, n_img,
                                           cross_attention_kwargs, start_time, timeout, slot=slot)
         else:
-            if slot:
-                raise NotImplementedError("generation slots (two generations in flight) exist for the fused DPM++ 2M loop only")
             latents = self._denoise_protocol(sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                                              guidance_rescale, n_img, cross_attention_kwargs, eta,
                                              num_inference_steps, sampler_opt, seed, start_time, timeout,
-                                             control_hook=control_hook, preview=preview)
+                                             control_hook=control_hook, preview=preview, slot=slot)
         if upscale:                                                                                          # :1176-1228
             res = self._hires_pass(latents, height, width, upscale_x, upscale_method, upscale_antialias, **hires)
             return latents_process + res if latent_processing == 1 else res
@@ -875,7 +873,8 @@ class StableDiffusionPipeline:
     # ---- protocol mode: the reference's model_fn closure (:1091-1171) + sampler call (:1172-1175)
     def _denoise_protocol(self, sampler, latents, sigmas, text, region_state, weight_func, guidance_scale,
                           guidance_rescale, n_img, cross_attention_kwargs, eta, steps, sampler_opt, seed, start_time,
-                          timeout, sampler_args=None, input_hook=None, control_hook=None, extra_input=None, preview=None):
+                          timeout, sampler_args=None, input_hook=None, control_hook=None, extra_input=None, preview=None,
+                          slot=0):
         """sampler_args: the keyword arguments for `sampler` when the caller built them itself (img2img's
         get_sampler_extra_args_i2i); input_hook(x, sigma, call_index) -> x: applied to the model input (inpainting's
         re-imposition of the known region, reference :1599-1612); extra_input [rows, c, h, w]: channels concatenated to the
@@ -899,8 +898,9 @@ class StableDiffusionPipeline:
             ckey = None if control is None else tuple(
                 ("cn", id(self.controlnet), tuple(tuple(i.shape) for i in (p["image"] if isinstance(p["image"], list) else [p["image"]])))
                 if p["kind"] == "controlnet" else ("ad", tuple(tuple(v.shape) for v in p["state"])) for p in control)
-            key = (n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
+            key = (("slot", slot), n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
                    if hasattr(weight_func, "__code__") else id(weight_func), None) + (() if ckey is None else (ckey,))
+            _lib.check(_lib.load_library().dsc_set_workspace_slot(slot), "dsc_set_workspace_slot")    # see _denoise_fused
             st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs,
                                    control=control)
             scratch = torch.zeros_like(latents, dtype=text.dtype)
@@ -935,7 +935,15 @@ class StableDiffusionPipeline:
 
             extra = sampler_args if sampler_args is not None else \
                 self.get_sampler_extra_args_t2i(sigmas, eta, steps, sampler_opt, latents, seed, sampler)
-            return sampler(model_fn, latents, **extra)
+            out = sampler(model_fn, latents, **extra)
+            done = st.get("done")
+            if done is None:
+                done = st["done"] = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(latents.device))
+            return out
+        if slot:
+            raise NotImplementedError("generation slots need the graph-backed model call (eps-prediction, CFG without rescale, "
+                                      "fp16, no per-call UNet inputs)")
 
         def model_fn(x, sigma):
             if start_time > 0 and timeout > 0:

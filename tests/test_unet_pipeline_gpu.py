@@ -1351,5 +1351,30 @@ def test_two_generations_in_flight_match_sequential(ops):
     assert not torch.equal(want[0], want[1])
     diffs = [[(o.float() - want[j].float()).abs().max().item() for o in got[j]] for j in range(2)]
     assert all(d == 0.0 for row in diffs for d in row), diffs
-    with pytest.raises(NotImplementedError):
-        pipe.txt2img(None, slot=1, fused=False, **jobs[0])
+    # protocol mode (any sampler, graph-backed model calls) in the slots: Euler, two threads, against slot 0 alone
+    ejobs = [dict(job, sampler_name="sample_euler", fused=False) for job in jobs]
+    ewant = [pipe.txt2img(None, **job)[0].clone() for job in ejobs]
+    for j, job in enumerate(ejobs):
+        with torch.cuda.stream(streams[j]):
+            pipe.txt2img(None, slot=j, **job)
+        torch.cuda.synchronize()
+    egot = [None, None]
+
+    def edrive(j):
+        try:
+            with torch.cuda.stream(streams[j]):
+                for _ in range(2):
+                    egot[j] = pipe.txt2img(None, slot=j, **ejobs[j])[0]
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=edrive, args=(j,)) for j in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert all(torch.equal(egot[j], ewant[j]) for j in range(2)) and not torch.equal(ewant[0], ewant[1])
+    with pytest.raises(NotImplementedError):                      # CFG rescale needs the eager model call: no slots there
+        pipe.txt2img(None, slot=1, fused=False, guidance_rescale=0.5, **jobs[0])
