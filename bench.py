@@ -42,8 +42,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6, help="timed generations (each = 25 denoising steps)")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8, help="timed generations (each = 25 denoising steps)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--denoise-steps", type=int, default=25)
