@@ -13,6 +13,13 @@ and region table before the timed region).  Synthetic data: random-init SD1.5-ar
 seeded text embeddings, rectangular 64-px-aligned region masks.  Inputs are resident in HBM when
 the timed region starts; the final latents stay on the device (VAE decode is outside the path).
 
+`--in-flight N` (default 2): the K generations are driven by N host threads, each with its own stream and generation
+slot (static buffers, captured step, packed K/V, library workspace - DESIGN.md section 6), pulling the next generation
+from a shared queue.  Every generation is still ONE batch-1 image with its own inputs and results equal to the
+one-at-a-time results bit for bit; what changes is that the GPU interleaves two of them.  `value` / `ms_per_step` are
+total images / wall time (throughput); `one_generation_at_a_time` on the same line repeats the K generations with one in
+flight (`--in-flight 1` makes that the headline): its ms_per_generation is the latency of one image.
+
 Extra objects on the JSON line:
   roofline     - the region cross-attention forward kernel (`xp_fwd`, L=4096 level of the same workload) timed live with
                  HIP events around graph-captured back-to-back launches on the stream they run on: algorithmic bytes
@@ -22,6 +29,7 @@ Extra objects on the JSON line:
                  (4*L^2*C FLOPs per row).
   roofline_conv3x3   - the 3x3 convolution kernel (64x64, 320->320, the most frequent one) against the same peak
   roofline_at_8_images - the same three kernels at Bc = 16 (BASELINE configs[2]: 8 images per GPU): achieved / frac / launch time
+  one_generation_at_a_time - see above
   cpu_baseline - the oracle (oracle/unet_ref.py, torch fp32, op-for-op unfused like the reference) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
