@@ -231,13 +231,21 @@ def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sampl
     sig = sigmas.float().cpu().tolist()
     lat = latents.float().cpu() * math.sqrt(sig[0] ** 2 + 1)
     t0 = time.perf_counter()
-    unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), region_state, guidance, steps_limit=sample_steps)
+    ref = unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), region_state, guidance, steps_limit=sample_steps)
     dt = time.perf_counter() - t0
     per_image = dt / sample_steps * total_steps
     return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{sample_steps} of {total_steps} denoising steps of one 512x512 image through the fp32 torch oracle "
                       f"({dt:.1f} s), scaled x{total_steps}/{sample_steps}",
-            "seconds_per_image_extrapolated": round(per_image, 1)}
+            "seconds_per_image_extrapolated": round(per_image, 1)}, ref
+
+
+def gpu_sample(pipe, sigmas, text, region_state, latents, guidance, sample_steps):
+    """the product loop on the same truncated schedule as the cpu_baseline sample (same inputs, fp16, HIP kernels)"""
+    import inspect
+    wf = inspect.signature(pipe.txt2img).parameters["weight_func"].default
+    x0 = latents * (sigmas[0] ** 2 + 1) ** 0.5                           # as txt2img does (reference model_k_diffusion.py:1043)
+    return pipe._denoise_fused(x0, sigmas[:sample_steps + 1], text, region_state, wf, guidance, latents.shape[0], {}, -1, 0)
 
 
 def main():
@@ -406,7 +414,13 @@ def main():
             rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)
             sig = pipe.get_sigmas(a.denoise_steps, {"scheduler": "karras"}).half()
             text = torch.cat([emb[0:1], emb[1:2]]).half()
-            res["cpu_baseline"] = cpu_baseline(unet, cfg, sig, text, rs, lat[:1], 7.5, a.cpu_sample_steps, a.denoise_steps)
+            res["cpu_baseline"], ref = cpu_baseline(unet, cfg, sig, text, rs, lat[:1], 7.5, a.cpu_sample_steps, a.denoise_steps)
+            # the checker's other use: the timed GPU path and the CPU baseline computed the same thing on this sample
+            got = gpu_sample(pipe, sig.to(dev), text.to(dev), rs, lat[:1], 7.5, a.cpu_sample_steps).float().cpu()
+            err = (got - ref).abs()
+            res["cpu_baseline"]["gpu_vs_cpu_on_the_sample"] = {
+                "max_abs_err": round(err.max().item(), 5), "mean_abs_err": round(err.mean().item(), 6),
+                "ref_max_abs": round(ref.abs().max().item(), 4), "note": "latents after the sampled steps: fp16 HIP path vs fp32 oracle"}
         print(json.dumps(res), flush=True)
     if dist:
         td.barrier()
