@@ -31,7 +31,8 @@ Extra objects on the JSON line:
   roofline_at_8_images - the same three kernels at Bc = 16 (BASELINE configs[2]: 8 images per GPU): achieved / frac / launch time
   one_generation_at_a_time - see above
   cpu_baseline - the oracle (oracle/unet_ref.py, torch fp32, op-for-op unfused like the reference) timed on this
-                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+                 box's host cores on a bounded sample of the same workload (rank 0, N=1 only); its
+                 gpu_vs_cpu_on_the_sample = the product loop on the same sample against the oracle's latents.
 """
 import argparse
 import json
