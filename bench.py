@@ -311,6 +311,8 @@ def main():
 
     out = None
     nfl = 1 if (a.decode or a.no_graph) else max(1, a.in_flight)     # slots exist for the captured denoising loop
+    if nfl > 4:
+        raise SystemExit("--in-flight: at most 4 generation slots (dsc_set_workspace_slot)")
     streams = [torch.cuda.Stream() for _ in range(nfl)] if nfl > 1 else None
     if nfl > 1:
         torch.cuda.synchronize()
