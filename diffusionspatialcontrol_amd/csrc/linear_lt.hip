@@ -6,8 +6,9 @@
 // proj_out / conv_shortcut): torch offers either the bias epilogue (F.linear) or beta*C (addmm), never both, so each of
 // the 33 such GEMMs per UNet step was followed by a separate elementwise add launch.  hipBLASLt is a plain library GEMM
 // here (column-major view: D^T[N x M] = W[N x K] . X^T[K x M], bias along D^T's rows = output channels).  The one choice
-// made on top of it: which of the heuristic's candidate algorithms runs - the first call of a shape times up to DSC_LT_TUNE (default 16) of them
-// on the caller's operands and keeps the fastest (DSC_LT_TUNE=0: the heuristic's first choice, as torch takes it).
+// made on top of it: which of the heuristic's candidate algorithms runs - the first call of a shape times up to
+// DSC_LT_TUNE (default 16) of them on the caller's operands, in the cache state of a UNet step (tune_plan), and keeps the
+// fastest (DSC_LT_TUNE=1: the heuristic's first choice, as torch takes it).
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 #include <stdint.h>
