@@ -354,6 +354,7 @@ def main():
         if errs:
             raise errs[0]
         out = next(o for o in reversed(outs) if o is not None)
+        slot_outs = [o for o in outs if o is not None]
     else:
         for _ in range(a.steps):
             out = generate()
@@ -366,7 +367,7 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         dt = tt.item()
     finite = bool(torch.isfinite(out).all().item())
-    dt_seq = None
+    dt_seq, slots_agree = None, None
     if nfl > 1:                                             # the same K generations one after the other (slot 0), for reference
         if dist:
             td.barrier()
@@ -379,6 +380,9 @@ def main():
         if dist:
             td.barrier()
         dt_seq = time.perf_counter() - t0
+        # every generation has the same inputs and every kernel is bit-reproducible: the slots' last results and the
+        # one-at-a-time result must be EQUAL - a free check on every run that the generations in flight did not interfere
+        slots_agree = all(torch.equal(o, out) for o in slot_outs)
         if dist:
             tt = torch.tensor([dt_seq], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
@@ -396,6 +400,7 @@ def main():
                                    f"{nfl} generation(s) in flight per GPU",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
                        "generations_in_flight": nfl, "images_per_generation": n_img,
+                       "slots_equal_one_at_a_time": slots_agree if nfl > 1 else None,
                        "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite, "vae_decode_in_timed_region": bool(a.decode)},
         }
         if dt_seq is not None:
