@@ -88,6 +88,9 @@ def test_groupnorm_of_concatenation(ops, B, C1, C2, h, w, G, act):
     want_cat = torch.cat([x1, x2], dim=1).contiguous(memory_format=cl)
     assert cat.is_contiguous(memory_format=cl) and torch.equal(cat, want_cat)
     assert torch.equal(y, ops.groupnorm_silu_nhwc(want_cat, G, gamma, beta, 1e-5, act))
+    add = (torch.randn(B, C1 + C2, generator=g) * 0.8).half().cuda()            # the fused per-(b, c) term rides along
+    y_add, cat_add = ops.groupnorm_silu_nhwc_cat(x1, x2, G, gamma, beta, 1e-5, act, add=add)
+    assert torch.equal(cat_add, want_cat) and torch.equal(y_add, ops.groupnorm_silu_nhwc(want_cat, G, gamma, beta, 1e-5, act, add=add))
     ref = F.group_norm(want_cat.float(), G, gamma.float(), beta.float(), 1e-5)
     ref = F.silu(ref) if act else ref
     assert (y.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
