@@ -72,3 +72,24 @@ def test_ops_fail_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_lib, "lib_path", lambda: os.path.join("/nonexistent", "libdsc_hip.so"))
     with pytest.raises(dsc.DscLibraryError):
         _lib.load_library()
+
+
+def test_workspace_slot_and_concat_groupnorm_validation(lib):
+    """dsc_set_workspace_slot: four slots, thread-local; dsc_groupnorm_silu_nhwc_cat: argument checks before any launch"""
+    import threading
+    assert lib.dsc_set_workspace_slot(4) == -1 and lib.dsc_set_workspace_slot(-1) == -1
+    assert lib.dsc_set_workspace_slot(3) == 0
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.dsc_set_workspace_slot(1)))       # another thread, its own slot
+    t.start()
+    t.join()
+    assert seen == [0] and lib.dsc_set_workspace_slot(0) == 0
+    d = ctypes.c_void_p(0x1000)
+    cat = lambda **kw: lib.dsc_groupnorm_silu_nhwc_cat(  # noqa: E731
+        d, kw.get("x2", ctypes.c_void_p(0x2000)), kw.get("C1", 320), kw.get("cat", ctypes.c_void_p(0x3000)),
+        ctypes.c_void_p(0x4000), d, d, None, 0, 2, kw.get("C", 640), 64, 32, 1e-5, 1, 0, kw.get("ws", None), 0, None)
+    assert cat(x2=None) == -1 and cat(cat=None) == -1
+    assert cat(C1=640) == -1 and cat(C1=0) == -1          # both sources must contribute channels
+    assert cat(C1=12) == -2                               # 16-byte vectors must not straddle the seam
+    assert cat(cat=d) == -2                               # the concatenation must not alias a source
+    assert cat() == -3                                    # valid arguments, no workspace
