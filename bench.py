@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="generations in flight per GPU: N host threads, each with its own stream and generation slot (static "
                          "buffers, captured step, packed K/V, library workspace); every generation is still one batch-1 image")
+    ap.add_argument("--stall-seconds", type=float, default=120.0,
+                    help="in-flight leg: no generation completed for this long -> print the line with the one-at-a-time figure and exit")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-roofline", action="store_true",
                     help="skip roofline_at_8_images (profiling runs: its Bc = 16 launches of the same kernels would mix into the "
@@ -324,89 +326,53 @@ def main():
     else:
         for _ in range(a.warmup):
             out = generate()
-    if dist:
-        td.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if nfl > 1:
-        import threading
-        outs, errs = [None] * nfl, []
+    import contextlib
+    import threading
 
-        todo, todo_lock = iter(range(a.steps)), threading.Lock()
-
-        def drive(s_i):
-            try:
-                torch.cuda.set_device(dev)                  # the current device is per host thread
-                with torch.cuda.stream(streams[s_i]):
-                    while True:                             # a.steps generations in total, whichever slot is free next
-                        with todo_lock:
-                            if next(todo, None) is None:
-                                break
-                        outs[s_i] = generate(s_i)
-            except BaseException as e:                      # noqa: BLE001 - re-raised on the main thread
-                errs.append(e)
-
-        threads = [threading.Thread(target=drive, args=(i,)) for i in range(nfl)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errs:
-            raise errs[0]
-        out = next(o for o in reversed(outs) if o is not None)
-        slot_outs = [o for o in outs if o is not None]
-    else:
-        for _ in range(a.steps):
-            out = generate()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        dt = tt.item()
-    finite = bool(torch.isfinite(out).all().item())
-    dt_seq, slots_agree = None, None
-    if nfl > 1:                                             # the same K generations one after the other (slot 0), for reference
+    def timed(fn):
+        """K generations between barrier + synchronize on both sides; the MAX over ranks"""
         if dist:
             td.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        with torch.cuda.stream(streams[0]):
-            for _ in range(a.steps):
-                out = generate(0)
+        r = fn()
         torch.cuda.synchronize()
         if dist:
             td.barrier()
-        dt_seq = time.perf_counter() - t0
-        # every generation has the same inputs and every kernel is bit-reproducible: the slots' last results and the
-        # one-at-a-time result must be EQUAL - a free check on every run that the generations in flight did not interfere
-        slots_agree = all(torch.equal(o, out) for o in slot_outs)
+        dt_ = time.perf_counter() - t0
         if dist:
-            tt = torch.tensor([dt_seq], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
-            dt_seq = tt.item()
+            dt_ = tt.item()
+        return dt_, r
 
+    def one_at_a_time():
+        o = None
+        with (torch.cuda.stream(streams[0]) if streams else contextlib.nullcontext()):
+            for _ in range(a.steps):
+                o = generate(0)
+        return o
+
+    # Order: the one-at-a-time leg, the roofline / cpu_baseline legs, and only then the generations in flight - so that a
+    # complete line exists before the only leg in which two streams share the chip, and a stall there (never observed;
+    # hipBLASLt's stream-K kernels spin on each other's partial tiles) still ends with a valid line instead of a hung job.
+    dt_seq, out = timed(one_at_a_time)
+    finite = bool(torch.isfinite(out).all().item())
+    images = n_img * world * a.steps
+    res = None
     if rank == 0:
-        images = n_img * world * a.steps
         res = {
             "metric": "512x512 images/sec, SD1.5 25-step DPM++2M Karras with region-biased cross-attention",
-            "value": round(images / dt, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "value": round(images / dt_seq, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt_seq / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"SD1.5 {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
                                    f"{a.regions} region masks, {n_img} image(s) per generation, "
-                                   f"{nfl} generation(s) in flight per GPU",
+                                   f"1 generation(s) in flight per GPU",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
-                       "generations_in_flight": nfl, "images_per_generation": n_img,
-                       "slots_equal_one_at_a_time": slots_agree if nfl > 1 else None,
+                       "generations_in_flight": 1, "images_per_generation": n_img, "slots_equal_one_at_a_time": None,
                        "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite, "vae_decode_in_timed_region": bool(a.decode)},
         }
-        if dt_seq is not None:
-            res["one_generation_at_a_time"] = {"value": round(images / dt_seq, 4), "unit": "images/s",
-                                               "ms_per_generation": round(dt_seq / a.steps * 1e3, 2),
-                                               "note": "the same K generations with one in flight (latency of one image)"}
         res["roofline"] = roofline_region_xattn(dev, n_img)
         res["roofline_self_attn"] = roofline_self_attn(dev, n_img)
         res["roofline_conv3x3"] = roofline_conv3x3(dev, n_img)
@@ -429,6 +395,55 @@ def main():
             res["cpu_baseline"]["gpu_vs_cpu_on_the_sample"] = {
                 "max_abs_err": round(err.max().item(), 5), "mean_abs_err": round(err.mean().item(), 6),
                 "ref_max_abs": round(ref.abs().max().item(), 4), "note": "latents after the sampled steps: fp16 HIP path vs fp32 oracle"}
+    if nfl > 1:
+        progress = [0, time.monotonic()]
+        outs, errs = [None] * nfl, []
+        todo, todo_lock = iter(range(a.steps)), threading.Lock()
+
+        def drive(s_i):
+            try:
+                torch.cuda.set_device(dev)                  # the current device is per host thread
+                with torch.cuda.stream(streams[s_i]):
+                    while True:                             # a.steps generations in total, whichever slot is free next
+                        with todo_lock:
+                            if next(todo, None) is None:
+                                break
+                        outs[s_i] = generate(s_i)
+                        progress[0] += 1
+                        progress[1] = time.monotonic()
+            except BaseException as e:                      # noqa: BLE001 - re-raised on the main thread
+                errs.append(e)
+
+        def in_flight():
+            progress[1] = time.monotonic()
+            threads = [threading.Thread(target=drive, args=(i,), daemon=True) for i in range(nfl)]
+            for t in threads:
+                t.start()
+            while any(t.is_alive() for t in threads):
+                for t in threads:
+                    t.join(timeout=0.25)
+                if time.monotonic() - progress[1] > a.stall_seconds:
+                    if res is not None:
+                        res["config"]["in_flight_leg"] = (f"stalled after {progress[0]} of {a.steps} generations with {nfl} in "
+                                                          f"flight; value is the one-at-a-time figure")
+                        print(json.dumps(res), flush=True)
+                    os._exit(0)          # the line above is complete and says what happened; the stuck threads cannot be joined
+            if errs:
+                raise errs[0]
+            return [o for o in outs if o is not None]
+
+        dt, slot_outs = timed(in_flight)
+        # every generation has the same inputs and every kernel is bit-reproducible: the slots' last results and the
+        # one-at-a-time result must be EQUAL - a free check on every run that the generations in flight did not interfere
+        slots_agree = all(torch.equal(o, out) for o in slot_outs)
+        if res is not None:
+            res["one_generation_at_a_time"] = {"value": res["value"], "unit": "images/s", "ms_per_generation": res["ms_per_step"],
+                                               "note": "the same K generations with one in flight (latency of one image)"}
+            res["value"], res["ms_per_step"] = round(images / dt, 4), round(dt / a.steps * 1e3, 2)
+            res["config"].update({"generations_in_flight": nfl, "slots_equal_one_at_a_time": slots_agree,
+                                  "outputs_finite": finite and all(bool(torch.isfinite(o).all().item()) for o in slot_outs),
+                                  "workload": res["config"]["workload"].replace("1 generation(s) in flight", f"{nfl} generation(s) in flight")})
+    if res is not None:
         print(json.dumps(res), flush=True)
     if dist:
         td.barrier()
