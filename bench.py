@@ -18,7 +18,8 @@ slot (static buffers, captured step, packed K/V, library workspace - DESIGN.md s
 from a shared queue.  Every generation is still ONE batch-1 image with its own inputs and results equal to the
 one-at-a-time results bit for bit; what changes is that the GPU interleaves two of them.  `value` / `ms_per_step` are
 total images / wall time (throughput); `one_generation_at_a_time` on the same line repeats the K generations with one in
-flight (`--in-flight 1` makes that the headline): its ms_per_generation is the latency of one image.
+flight (`--in-flight 1` makes that the headline): its ms_per_generation is the latency of one image.  Leg order: one at a
+time, rooflines, cpu_baseline, then the generations in flight behind a stall watchdog (`--stall-seconds`).
 
 Extra objects on the JSON line:
   roofline     - the region cross-attention forward kernel (`xp_fwd`, L=4096 level of the same workload) timed live with
