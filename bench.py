@@ -60,9 +60,9 @@ def parse():
     ap.add_argument("--regions", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--miopen-find", action="store_true",
-                    help="let MIOpen time its solvers (cudnn.benchmark + MIOPEN_FIND_MODE=1) during warm-up.  Off by default: "
-                         "only the three stride-2 and the two 4-channel convolutions are still MIOpen's, the search no longer "
-                         "changes the result (6.19-6.23 vs 6.19-6.20 images/s) and its timing-based choice varies run to run")
+                    help="let MIOpen time its solvers (cudnn.benchmark + MIOPEN_FIND_MODE=1) during warm-up.  Off by default and "
+                         "without effect on the SD1.5 step: none of its convolutions is MIOpen's any more (only channel counts "
+                         "the hand-written kernels do not cover fall back to it)")
     ap.add_argument("--no-miopen-find", action="store_true", help="(default behaviour; kept for older command lines)")
     ap.add_argument("--deterministic-conv", action="store_true",
                     help="torch.backends.cudnn.deterministic: MIOpen then avoids its split-K (fp16 atomic) igemm kernels but "
@@ -71,7 +71,8 @@ def parse():
                     help="generations in flight per GPU: N host threads, each with its own stream and generation slot (static "
                          "buffers, captured step, packed K/V, library workspace); every generation is still one batch-1 image")
     ap.add_argument("--stall-seconds", type=float, default=120.0,
-                    help="in-flight leg: no generation completed for this long -> print the line with the one-at-a-time figure and exit")
+                    help="in-flight leg: no generation completed for this long -> print the line (status: stalled, value = the "
+                         "one-at-a-time figure) and exit with status 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batched-roofline", action="store_true",
                     help="skip roofline_at_8_images (profiling runs: its Bc = 16 launches of the same kernels would mix into the "
@@ -105,6 +106,15 @@ def synthetic_inputs(size, regions, S=77, ctx=768):
         m[(cells // 4) * 64:(3 * cells // 4) * 64, x0 * 64:x1 * 64] = 0
         state[w] = {"map": m, "weight": 0.5, "mask_outsides": 0.0}       # UI defaults app.py:1332-1336
     return emb, [pos.copy(), pos], state, tok
+
+
+def xattn_source_sha16():
+    """identifies the region cross-attention kernel source the PMC traffic figure was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("region_xattn_packed.hip", "xattn_shared.h"):
+        h.update(open(os.path.join(ROOT, "diffusionspatialcontrol_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def graph_launch_time_us(fn, launches=50, replays=10):
@@ -160,18 +170,30 @@ def roofline_region_xattn(dev, n_img):
     fwd = graph_launch_time_us(lambda: call(reuse_stats=True))
     alg_bytes = Bc * (2 * (2 * L * C + 2 * S * C) + 4 * L * S)
     achieved = alg_bytes / (fwd * 1e-6) / 1e9
-    traffic = None
+    traffic, traffic_note = None, None
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pj):
+    if os.path.exists(pj) and n_img == 1:                              # the PMC passes were taken at Bc = 2
         try:
-            traffic = json.load(open(pj)).get("xp_fwd_hbm_bytes_per_launch") if n_img == 1 else None   # measured at Bc=2
+            rec = json.load(open(pj))
+            if rec.get("kernel_source_sha16") == xattn_source_sha16():
+                traffic = rec.get("xp_fwd_hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 PMC passes of tools/pmc_xattn.py (profiles/pmc_traffic.json), taken on this kernel source"
+            else:
+                traffic_note = "profiles/pmc_traffic.json was measured on a different version of the kernel source: not reported"
         except Exception:  # noqa: BLE001
             traffic = None
+    # what the launch has to move now that K/V arrive packed and the table compressed: Q + out, the packed K/V images
+    # (21 KB per (b, h) at d = 40), uint16 row ids + the distinct rows
+    must_move = Bc * (2 * 2 * L * C) + packed.numel() * packed.element_size() \
+        + ids.numel() * ids.element_size() + rows.numel() * rows.element_size()
     return {"kernel": "xp_fwd<3,false> (region cross-attention forward, L=4096 C=320 S=77, Bc=%d)" % Bc,
             "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
             "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+            "traffic_note": traffic_note,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd, 2),
             "stats_plus_fwd_us": round(pair, 2),
+            "bytes_the_kernel_must_move": int(must_move),
+            "frac_of_peak_on_bytes_it_must_move": round(must_move / (fwd * 1e-6) / 8e12, 4),
             "note": "algorithmic bytes = SURVEY.md 8d per-row figure (6.60 MB incl. the dense fp32 table) x Bc rows; the kernel "
                     "itself reads the table as uint16 row ids + <=32 distinct rows"}
 
@@ -252,8 +274,29 @@ def gpu_sample(pipe, sigmas, text, region_state, latents, guidance, sample_steps
     return pipe._denoise_fused(x0, sigmas[:sample_steps + 1], text, region_state, wf, guidance, latents.shape[0], {}, -1, 0)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as CHILDREN (torch.distributed.run, one
+    process per GPU) before this process has touched the GPU - never an exec of a process that has - relay their output
+    (rank 0 prints the JSON line) and exit with the worst child status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: run `python bench.py "
+                         f"--gpus N` (it starts the N ranks itself) or `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N`")
     if a.miopen_find and not a.no_miopen_find:
         os.environ.setdefault("MIOPEN_FIND_MODE", "1")         # must be set before MIOpen initialises
         torch.backends.cudnn.benchmark = True                   # let MIOpen time its solvers per conv shape (warm-up only)
@@ -261,6 +304,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = world > 1
+    backend = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     local = local % torch.cuda.device_count()                 # (rehearsals put several ranks on one GPU)
@@ -330,6 +374,8 @@ def main():
     import contextlib
     import threading
 
+    own = [0.0]
+
     def timed(fn):
         """K generations between barrier + synchronize on both sides; the MAX over ranks"""
         if dist:
@@ -338,14 +384,25 @@ def main():
         t0 = time.perf_counter()
         r = fn()
         torch.cuda.synchronize()
+        own[0] = time.perf_counter() - t0                   # this rank's own time, before it waits for the others
         if dist:
             td.barrier()
         dt_ = time.perf_counter() - t0
         if dist:
-            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt_], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             td.all_reduce(tt, op=td.ReduceOp.MAX)
             dt_ = tt.item()
         return dt_, r
+
+    def per_rank():
+        """every rank's own time for its K generations (taken before the closing barrier), gathered: images/s per rank"""
+        fn_seconds = own[0]
+        mine = torch.tensor([fn_seconds], device=dev if dist and backend == "nccl" else "cpu", dtype=torch.float64)
+        if not dist:
+            return [round(n_img * a.steps / fn_seconds, 4)]
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(allr, mine)
+        return [round(n_img * a.steps / t.item(), 4) for t in allr]
 
     def one_at_a_time():
         o = None
@@ -358,6 +415,7 @@ def main():
     # complete line exists before the only leg in which two streams share the chip, and a stall there (never observed;
     # hipBLASLt's stream-K kernels spin on each other's partial tiles) still ends with a valid line instead of a hung job.
     dt_seq, out = timed(one_at_a_time)
+    rates_seq = per_rank()
     finite = bool(torch.isfinite(out).all().item())
     images = n_img * world * a.steps
     res = None
@@ -371,6 +429,7 @@ def main():
                                    f"{a.regions} region masks, {n_img} image(s) per generation, "
                                    f"1 generation(s) in flight per GPU",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
+                       "per_rank_images_per_s": rates_seq, "max_over_ranks_s": round(dt_seq, 4),
                        "generations_in_flight": 1, "images_per_generation": n_img, "slots_equal_one_at_a_time": None,
                        "hip_graph": bool(ops.GRAPHS_ENABLED), "outputs_finite": finite, "vae_decode_in_timed_region": bool(a.decode)},
         }
@@ -424,16 +483,20 @@ def main():
                 for t in threads:
                     t.join(timeout=0.25)
                 if time.monotonic() - progress[1] > a.stall_seconds:
+                    msg = f"stalled after {progress[0]} of {a.steps} generations with {nfl} in flight"
                     if res is not None:
-                        res["config"]["in_flight_leg"] = (f"stalled after {progress[0]} of {a.steps} generations with {nfl} in "
-                                                          f"flight; value is the one-at-a-time figure")
+                        res["status"] = "stalled"
+                        res["config"]["in_flight_leg"] = msg + "; value is the one-at-a-time figure"
                         print(json.dumps(res), flush=True)
-                    os._exit(0)          # the line above is complete and says what happened; the stuck threads cannot be joined
+                    print(f"bench.py: rank {rank}: {msg}", file=sys.stderr, flush=True)
+                    os._exit(3)          # a stall is a FAILURE (non-zero; under torchrun it takes the other ranks down too);
+                    #                      the stuck threads cannot be joined, hence _exit
             if errs:
                 raise errs[0]
             return [o for o in outs if o is not None]
 
         dt, slot_outs = timed(in_flight)
+        rates_fl = per_rank()
         # every generation has the same inputs and every kernel is bit-reproducible: the slots' last results and the
         # one-at-a-time result must be EQUAL - a free check on every run that the generations in flight did not interfere
         slots_agree = all(torch.equal(o, out) for o in slot_outs)
@@ -442,6 +505,7 @@ def main():
                                                "note": "the same K generations with one in flight (latency of one image)"}
             res["value"], res["ms_per_step"] = round(images / dt, 4), round(dt / a.steps * 1e3, 2)
             res["config"].update({"generations_in_flight": nfl, "slots_equal_one_at_a_time": slots_agree,
+                                  "per_rank_images_per_s": rates_fl, "max_over_ranks_s": round(dt, 4),
                                   "outputs_finite": finite and all(bool(torch.isfinite(o).all().item()) for o in slot_outs),
                                   "workload": res["config"]["workload"].replace("1 generation(s) in flight", f"{nfl} generation(s) in flight")})
     if res is not None:

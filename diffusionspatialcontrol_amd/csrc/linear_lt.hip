@@ -55,7 +55,14 @@ thread_local int t_ws_slot = 0;
 std::mutex g_mu;
 
 void* workspace_for() { return g_ws_pool[t_ws_slot]; }
+bool allow_workspace() {
+    static const bool v = [] { const char* e = getenv("DSC_LT_ALLOW_WORKSPACE"); return e && atoi(e) != 0; }();
+    return v;
+}
+// the size the library is TOLD it may use: 0 unless the workspace-needing algorithms were asked for (A/B timing only)
+size_t ws_bytes() { return allow_workspace() ? kWsBytes : 0; }
 std::map<std::tuple<int64_t, int, int, int64_t, int64_t, int64_t, int, int>, Plan> g_plans;
+long long g_stat_seen = 0, g_stat_dropped_ws = 0;          // heuristic candidates seen / dropped for needing a workspace
 
 bool build_plan(Plan& p, int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, bool bias, bool res) {
     if (hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return false;
@@ -75,16 +82,32 @@ bool build_plan(Plan& p, int64_t M, int N, int K, int64_t ldx, int64_t ldr, int6
     if (hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16F, N, M, ldo) != HIPBLAS_STATUS_SUCCESS) return false;
     hipblasLtMatmulPreference_t pref = nullptr;
     if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return false;
-    const uint64_t maxws = kWsBytes;
+    const uint64_t maxws = ws_bytes();                     // 0: the heuristic itself then only returns workspace-free algorithms
     hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
     hipblasLtMatmulHeuristicResult_t r[kMaxCand];
     int n = 0;
-    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, tune_count(), r, &n);
+    // ask for more than will be timed: the workspace filter below drops some
+    const int want = tune_count() * 2 < kMaxCand ? tune_count() * 2 : kMaxCand;
+    const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.d, pref, want, r, &n);
     hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || n < 1) return false;
-    for (int i = 0; i < n; ++i)
-        if (r[i].state == HIPBLAS_STATUS_SUCCESS && r[i].workspaceSize <= kWsBytes) p.cand[p.n_cand++] = r[i].algo;
-    if (p.n_cand < 1) return false;
+    // Only algorithms that need NO workspace are eligible.  The ones that do are hipBLASLt's stream-K / split-K kernels:
+    // persistent workgroups that publish partial tiles and arrival flags in the workspace and SPIN until the workgroup
+    // holding the other part of their tile has published.  That is live only while every workgroup of the launch is
+    // co-resident (or dispatched in index order with the waited-for ones first); with a second stream's kernels occupying
+    // CUs - two generations in flight, or the candidate-pair timing experiment that hung in round 1 - a spinning
+    // workgroup can hold the CU its partner needs, and nothing bounds the wait.  A workspace-free algorithm has no
+    // inter-workgroup dependency at all: each workgroup owns its output tiles, so it finishes under ANY residency.
+    // (DSC_LT_ALLOW_WORKSPACE=1 restores the old candidate set for A/B timing; never the default.)
+    const bool allow_ws = allow_workspace();
+    for (int i = 0; i < n; ++i) {
+        if (r[i].state != HIPBLAS_STATUS_SUCCESS) continue;
+        ++g_stat_seen;
+        if (r[i].workspaceSize != 0) ++g_stat_dropped_ws;
+        if (r[i].workspaceSize == 0 || (allow_ws && r[i].workspaceSize <= kWsBytes)) p.cand[p.n_cand++] = r[i].algo;
+    }
+    if (p.n_cand < 1) return false;                          // the caller falls back to its own kernels (ops.linear)
+    if (p.n_cand > tune_count()) p.n_cand = tune_count();
     p.algo = p.cand[0];
     p.ok = true;
     return true;
@@ -127,7 +150,7 @@ void tune_plan(Plan& p, const void* x, const void* w, const void* residual, void
             (void)hipMemcpyAsync(xcopy, x, xbytes, hipMemcpyDeviceToDevice, stream);
             (void)hipEventRecord(e0, stream);
             good = hipblasLtMatmul(g_handle, p.desc, &alpha, w, p.a, x, p.b, &beta, c, p.c, out, p.d, &p.cand[i], g_ws,
-                                   kWsBytes, stream) == HIPBLAS_STATUS_SUCCESS;
+                                   ws_bytes(), stream) == HIPBLAS_STATUS_SUCCESS;
             (void)hipEventRecord(e1, stream);
             float ms = 0.f;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) good = false;
@@ -141,6 +164,11 @@ void tune_plan(Plan& p, const void* x, const void* w, const void* residual, void
 }
 
 }  // namespace
+
+extern "C" void dsc_linear_lt_stats(long long out[3]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    out[0] = (long long)g_plans.size(); out[1] = g_stat_seen; out[2] = g_stat_dropped_ws;
+}
 
 extern "C" int dsc_set_workspace_slot(int slot) {
     if (slot < 0 || slot >= kWsPool) return DSC_ERR_BAD_ARG;
@@ -181,6 +209,6 @@ extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias,
     const float alpha = 1.f, beta = residual ? 1.f : 0.f;
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta,
                                                residual ? residual : out, plan->c, out, plan->d, &plan->algo,
-                                               workspace_for(), kWsBytes, hs);
+                                               workspace_for(), ws_bytes(), hs);
     return st == HIPBLAS_STATUS_SUCCESS ? DSC_OK : DSC_ERR_LAUNCH;
 }

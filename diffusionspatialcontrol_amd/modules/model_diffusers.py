@@ -218,7 +218,7 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
         ckey = None if control is None else (("cn", id(self.controlnet), tuple(
             tuple(i.shape) for i in (control["image"] if isinstance(control["image"], list) else [control["image"]]))),)
         key = ("diffusers", n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype,
-               id(weight_func.__code__) if hasattr(weight_func, "__code__") else id(weight_func), ckey)
+               self._weight_func_key(weight_func), ckey)
         st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, ca_kwargs,
                                control=static_control, n_std_groups=1)
         for i, t in enumerate(ts):

@@ -37,6 +37,7 @@ import torch
 from .. import _lib, ops
 from . import sampling
 from .encode_region_map_function import encode_region_map
+from .attention_modify import weight_func_is_default
 from .external_k_diffusion import CompVisDenoiser, CompVisVDenoiser
 
 
@@ -898,8 +899,8 @@ class StableDiffusionPipeline:
             ckey = None if control is None else tuple(
                 ("cn", id(self.controlnet), tuple(tuple(i.shape) for i in (p["image"] if isinstance(p["image"], list) else [p["image"]])))
                 if p["kind"] == "controlnet" else ("ad", tuple(tuple(v.shape) for v in p["state"])) for p in control)
-            key = (("slot", slot), n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
-                   if hasattr(weight_func, "__code__") else id(weight_func), None) + (() if ckey is None else (ckey,))
+            key = (("slot", slot), n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype,
+                   self._weight_func_key(weight_func), None) + (() if ckey is None else (ckey,))
             _lib.check(_lib.load_library().dsc_set_workspace_slot(slot), "dsc_set_workspace_slot")    # see _denoise_fused
             st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, cross_attention_kwargs,
                                    control=control)
@@ -1025,7 +1026,15 @@ class StableDiffusionPipeline:
         st = self._graphs.get(key)
         comp_cpu = self._compress_tables(region_state)
         ack = self._added_cond_kwargs
-        if st is not None and (st["compressed"] is None) == (comp_cpu is None):
+        # Which tables does the captured step READ?  The prepared-operand kernels read the compressed (ids, rows) buffers;
+        # every other route (a table with more than 32 distinct rows, a custom weight_func, prompts beyond the chunked
+        # kernels) reads the DENSE table - so the graph must be given a static device copy that each generation refreshes in
+        # place, never the first generation's own tensors (a later generation with the same shapes would replay old masks).
+        need_dense = isinstance(region_state, dict) and bool(region_state) and (
+            comp_cpu is None or self._weight_func_key(weight_func) != "default" or text.shape[1] > 96
+            or not self._all_cross_attention_packable())
+        if (st is not None and (st["compressed"] is None) == (comp_cpu is None)
+                and (st["dense"] is None) == (not need_dense)):
             done = st.get("done")
             if done is not None:         # the slot's buffers may last have been driven from another stream
                 torch.cuda.current_stream(text.device).wait_event(done)
@@ -1044,16 +1053,21 @@ class StableDiffusionPipeline:
             "t": torch.zeros(rows, device=dev, dtype=torch.float32),
             "sigma": torch.ones(1, device=dev, dtype=torch.float32),
             "text": text.clone(),
-            "compressed": None, "region_state": region_state,
+            "compressed": None, "dense": None,
+            "weight_func": weight_func,          # kept alive: the key holds its id
             "image_embeds": None if ack is None else [e.clone() for e in ack["image_embeds"]],
         }
         if comp_cpu is not None:
             st["compressed"] = {L: (ids.to(dev), rws.to(dev)) for L, (ids, rws) in comp_cpu.items()}
+        if need_dense:
+            st["dense"] = {L: w.to(device=dev, dtype=torch.float32).contiguous().clone() for L, w in region_state.items()}
         st.update(self._control_buffers(control))
         self._refresh_text_kv(st["text"])
         kw = dict(cross_attention_kwargs)
-        kw["region_prompt"] = {"region_state": region_state, "compressed": st["compressed"], "sigma": st["sigma"],
-                               "weight_func": weight_func, "n_std_groups": n_img if n_std_groups is None else n_std_groups}
+        # without a dense copy the dict only supplies the level keys / shapes: no kernel of the captured step reads it
+        kw["region_prompt"] = {"region_state": st["dense"] if need_dense else region_state, "compressed": st["compressed"],
+                               "sigma": st["sigma"], "weight_func": weight_func,
+                               "n_std_groups": n_img if n_std_groups is None else n_std_groups}
 
         ukw = {} if ack is None else {"added_cond_kwargs": {"image_embeds": st["image_embeds"]}}
 
@@ -1091,6 +1105,21 @@ class StableDiffusionPipeline:
         self._graphs[key] = st
         return st
 
+    def _all_cross_attention_packable(self):
+        """every cross-attention layer's head dim has a packed text K/V image (_refresh_text_kv), i.e. runs the
+        prepared-operand kernels that read the compressed table"""
+        from .u_net_condition_modify import Attention
+        for m in self.unet.modules():
+            if isinstance(m, Attention) and m.is_cross_attention:
+                d = m.to_q.weight.shape[0] // m.heads
+                if d % 8 != 0 or d > 160:
+                    return False
+        return True
+
+    @staticmethod
+    def _weight_func_key(weight_func):
+        return "default" if (weight_func is None or weight_func_is_default(weight_func)) else id(weight_func)
+
     @staticmethod
     def _slot_of(key):
         return key[0][1] if isinstance(key[0], tuple) and key[0][:1] == ("slot",) else 0
@@ -1111,6 +1140,10 @@ class StableDiffusionPipeline:
 
     @staticmethod
     def _upload_tables(st, comp_cpu, region_state):
+        if st["dense"] is not None:              # the dense tables the captured step reads: refreshed in place
+            for L, dst in st["dense"].items():
+                src = region_state[L]
+                dst.copy_(src.pin_memory() if not src.is_cuda else src, non_blocking=True)
         if comp_cpu is None:
             return
         for L, (ids, rws) in comp_cpu.items():
@@ -1170,8 +1203,11 @@ class StableDiffusionPipeline:
         ack = getattr(self, "_added_cond_kwargs", None)
         ip_key = None if ack is None else (tuple(tuple(e.shape) for e in ack["image_embeds"]),
                                            id(getattr(self.unet, "encoder_hid_proj", None)))
-        key = (("slot", slot), n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype, id(weight_func.__code__)
-               if hasattr(weight_func, "__code__") else id(weight_func), ip_key)
+        # a callable that behaves as the default `w * sigma * qk.std()` (app.py:1004 builds a fresh lambda per request) runs
+        # the fused kernels whatever object it is; any other callable is baked into the captured step, so the key is the
+        # OBJECT (two closures of one code object may capture different values) and the step keeps it alive
+        key = (("slot", slot), n_img, tuple(latents.shape), levels, tuple(text.shape), text.dtype,
+               self._weight_func_key(weight_func), ip_key)
         if latents.is_cuda:
             # generation slots: each keeps its own static buffers, captured step, packed K/V and library-GEMM workspace, so
             # two generations can be in flight on two streams (one host thread per slot)

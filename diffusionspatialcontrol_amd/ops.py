@@ -379,16 +379,18 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
     M = 1
     for v in lead:
         M *= v
-    ok = (USE_DSC_GEMM and x.dtype == torch.float16 and weight.dtype == torch.float16 and K % 64 == 0 and N % 64 == 0
-          and M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K and x.stride(-1) == 1 and weight.is_contiguous()
-          and (not geglu or (bias is not None and residual is None and (N // 2) % 32 == 0)))
+    # `can`: dsc_linear_f16 is ABLE to run the shape; `ok`: it is also the faster choice (row / K thresholds)
+    can = (USE_DSC_GEMM and x.dtype == torch.float16 and weight.dtype == torch.float16 and K % 64 == 0 and N % 64 == 0
+           and x.stride(-1) == 1 and weight.is_contiguous()
+           and (not geglu or (bias is not None and residual is None and (N // 2) % 32 == 0)))
     x2 = None
-    if ok:
+    if can:
         x2 = x.reshape(M, K)                      # a view when the leading dims collapse (the token-major case)
-        ok = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
-    if ok and residual is not None:
+        can = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
+    if can and residual is not None:
         r2 = residual.reshape(M, N)
-        ok = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
+        can = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
+    ok = can and M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K
     if not ok:
         if ((USE_LT_RESIDUAL if residual is not None else USE_LT_ALL) and x.dtype == torch.float16 and K % 8 == 0
                 and N % 8 == 0 and M >= 8 and not (geglu and residual is not None)):
@@ -406,6 +408,10 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
                 if rc == 0:
                     out = out.reshape(*lead, N)
                     return globals()["geglu"](out) if geglu else out
+        # dsc_linear_lt_f16 declined (no workspace-free library algorithm for the shape, linear_lt.hip): the hand-written
+        # kernel takes it when it can, so that no GEMM of the step reaches a library algorithm this package did not vet
+        ok = can
+    if not ok:
         y = torch.nn.functional.linear(x, weight, bias)
         if geglu:
             return globals()["geglu"](y)

@@ -300,6 +300,10 @@ int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void
  * streams drives each from its own thread / slot, so that neither the eager GEMMs nor the ones baked into the two captured
  * step graphs share a workspace.  Thread-local; returns DSC_ERR_BAD_ARG outside 0..3. */
 int dsc_set_workspace_slot(int slot);
+/* Diagnostic: out[0] = shapes planned so far, out[1] = library candidate algorithms the heuristic offered, out[2] = how
+ * many of those need a workspace (stream-K / split-K kernels whose workgroups wait on each other's partial tiles) and were
+ * therefore NOT eligible: dsc_linear_lt_f16 only ever runs workspace-free algorithms, which finish under any residency. */
+void dsc_linear_lt_stats(long long out[3]);
 
 /*
  * Few-row linear (M <= 8) for the time-embedding path: y[m,n] = act(sum_k x[m,k] w[n,k] + bias[n]) - `Timesteps` +

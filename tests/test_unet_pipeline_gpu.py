@@ -106,7 +106,7 @@ def test_groupnorm_of_concatenation_rejects(ops):
 
 @pytest.mark.parametrize("B,H,L,d", [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160),
                                      (1, 4, 100, 64), (2, 10, 576, 64), (3, 5, 33, 16), (2, 8, 144, 160), (1, 2, 2304, 40),
-                                     (2, 20, 1024, 64), (1, 1, 1, 8)])
+                                     (2, 20, 1024, 64), (1, 1, 1, 8), (2, 8, 9216, 40), (2, 8, 4000, 40), (16, 8, 1024, 80)])
 def test_self_attention(ops, B, H, L, d):
     """flash self-attention vs torch fp32 softmax(QK^T/sqrt(d))V on the same fp16-representable inputs.
     Tolerance: P is packed to fp16 for the PV MFMA and the output is fp16: 2e-3 absolute on |out| <= ~1."""

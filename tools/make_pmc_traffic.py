@@ -1,0 +1,77 @@
+"""profiles/pmc_traffic.json from the two rocprofv3 PMC passes of tools/pmc_xattn.py:
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -- python3 tools/pmc_xattn.py
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -- python3 tools/pmc_xattn.py
+    python tools/make_pmc_traffic.py <counter_collection.csv of pass 1> <... of pass 2> [tag]
+
+Separate passes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2: MI355X_MICROARCH.md, rocprofv3 PMC slots).  gfx950
+correction (same guide, HBM section): FETCH_SIZE under-counts wide reads - exactly 1/2 for full-line 16 B/lane streams, other
+widths uncalibrated - so the factor is calibrated IN-PATTERN on `xp_stats`, whose HBM reads are known (Q once + the packed K
+images), on the cold launches (a 512 MiB fill between launches: the counters then see memory traffic, not cache hits).
+WRITE_SIZE reads exactly.  The result is stamped with the hash of the kernel source it was measured on; bench.py reports
+`traffic: null` when the source has changed since.
+"""
+import csv
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+Bc, H, L, S, d = 2, 8, 4096, 77, 40                      # tools/pmc_xattn.py's shape
+C = H * d
+N_COLD = 12                                              # its first 12 launch pairs follow a cache-evicting fill
+
+
+def sha16():
+    h = hashlib.sha256()
+    for f in ("region_xattn_packed.hip", "xattn_shared.h"):
+        h.update(open(os.path.join(ROOT, "diffusionspatialcontrol_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def per_kernel(path, counter):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"]
+        key = "xp_fwd" if "xp_fwd<" in name else "xp_stats" if "xp_stats<" in name else "xp_fused" if "xp_fused<" in name else None
+        if key:
+            out.setdefault(key, []).append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fpath, wpath = sys.argv[1], sys.argv[2]
+    tag = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    fetch, write = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
+    cold = lambda v: sum(v[:N_COLD]) / len(v[:N_COLD])                          # noqa: E731
+    rec = {"kernel_source_sha16": sha16(), "shape": {"Bc": Bc, "H": H, "L": L, "S": S, "d": d}, "how": {}}
+    how = rec["how"]
+    fwd_key = "xp_fwd" if "xp_fwd" in fetch else "xp_fused"
+    how["FETCH_SIZE_KB_raw"] = cold(fetch[fwd_key])
+    how["WRITE_SIZE_KB_raw"] = cold(write[fwd_key])
+    factor = 2.0                                                                  # the guide's full-line figure
+    if "xp_stats" in fetch:
+        how["xp_stats_FETCH_SIZE_KB_raw"] = cold(fetch["xp_stats"])
+        pack_bytes = 21504 * Bc * H if d == 40 else 0                            # packed K+V image per (b, h); stats reads the K half
+        known = Bc * L * C * 2 + pack_bytes / 2
+        factor = known / (how["xp_stats_FETCH_SIZE_KB_raw"] * 1024.0)
+        how["calibrated_on"] = "xp_stats (known reads: Q once + the packed K images)"
+    else:
+        how["calibrated_on"] = "not calibrated in-pattern (no xp_stats launch in the trace): the guide's x2 for wide reads"
+    how["fetch_calibration_factor"] = round(factor, 4)
+    rec["xp_fwd_hbm_bytes_per_launch"] = int(how["FETCH_SIZE_KB_raw"] * 1024 * factor + how["WRITE_SIZE_KB_raw"] * 1024)
+    rec["kernel"] = fwd_key
+    how["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_xattn.py), averages over the "
+                   f"{N_COLD} launches that follow a 512 MiB fill")
+    json.dump(rec, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    shutil.copy(fpath, os.path.join(ROOT, "profiles", f"{tag}_pmc_xattn_FETCH_SIZE.csv"))
+    shutil.copy(wpath, os.path.join(ROOT, "profiles", f"{tag}_pmc_xattn_WRITE_SIZE.csv"))
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()
