@@ -9,6 +9,7 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f16x_t __attribute__((ext_vector_type(16)));
 typedef float f4x_t __attribute__((ext_vector_type(4)));
+typedef float f2x_t __attribute__((ext_vector_type(2)));
 
 #define DSC_WAVE 64
 

@@ -3,18 +3,29 @@
 // Replaces `F.scaled_dot_product_attention(query, key, value)` on the self-attention branch of the processors
 // (source/modules/attention_modify.py:483-485) for the UNet's head dims 40 / 64 / 80 / 160.
 // The L x L score matrix is never materialised: per 32-query-row wave, KV tiles of 64 keys stream through LDS with an
-// online softmax (running max m, running sum l per query row).
+// online softmax (running max per query row, lazily updated).
 //
 // MI355X mapping (64-wide waves, MFMA 32x32x16 f16):
+//   * K / V tiles go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`: 1 KiB per wave instruction, NO register
+//     destination - nothing for the compiler to move, copy or spill between issue and wait; the first version staged
+//     through registers with asm loads whose destinations the compiler could not see and faulted at 3 waves per SIMD).
+//     The LDS image is lane-linear, so the padded row layout is made on the SOURCE side: lane l of piece j fetches the
+//     16-byte chunk that belongs at LDS chunk 64 j + l; pad chunks and keys beyond S carry an out-of-range buffer
+//     offset and the hardware deposits zeros.  Tile t+1 is in flight while tile t is multiplied: one `s_waitcnt
+//     vmcnt(0)` + ONE raw s_barrier per tile (it publishes tile t and proves every wave has left tile t-1's buffer).
 //   * S^T[kv, q] = K[kv, :] . Q[q, :]  ("swapped" product: A = K rows from LDS, B = Q^T kept in registers for the whole
-//     kernel) puts ONE query row on each lane (q = lane & 31) with half of the tile's 64 scores in its registers, so
-//     max / exp2 / sum are lane-local plus one exchange with lane ^ 32;
-//   * O^T[d, q] += V^T[d, kv] . P^T[kv, q]: the fp16-packed probabilities are already the B operand (k order
-//     permuted inside each 16-step, cdna_hip_programming.md section 3 "accumulator tile as the next MFMA's operand"); the A
-//     operand V^T comes from the ROW-MAJOR V tile in LDS through ds_read_b64_tr_b16 (hardware transpose), two reads
-//     per MFMA, conflict-free with a row stride of 96 / 160 halves;
-//   * K / V tiles are double-buffered in LDS: the global loads of tile t+1 are issued before the MFMAs of tile t and
-//     written after them (one barrier per tile);
+//     kernel, pre-multiplied by scale * log2 e) puts ONE query row on each lane (q = lane & 31) with half of the tile's
+//     64 scores in its registers.  The chain's initial accumulator is -m (the row's running max, 16 registers holding the
+//     same value, rewritten only when the max moves): the MFMA result IS  s - m  and  p = exp2(result)  - no scale, no
+//     subtract, 32 v_exp_f32 + 16 v_max3_f32 + 16 v_cvt_pk_f16_f32 per lane and tile;
+//   * lazy rescale (tau = 8): the running max moves only when some row's scores exceed it by 2^8 - then (rare, wave-
+//     uniform branch) the accumulators are rescaled; P <= 256 in fp16, sums in fp32;
+//   * O^T[d, q] += V^T[d, kv] . P^T[kv, q]: the fp16-packed probabilities are already the B operand (k order permuted
+//     inside each 16-step, cdna_hip_programming.md section 3 "accumulator tile as the next MFMA's operand"); the A operand
+//     V^T comes from the ROW-MAJOR V tile in LDS through ds_read_b64_tr_b16 (hardware transpose);
+//   * row sums for free where the head dim leaves padding in the last 32-channel tile (d = 40, 80): the lanes that would
+//     read V's padding columns 16 NK .. 16 NK + 15 read a constant LDS region [1, 0, ..., 0] instead, so output channel
+//     16 NK of the PV product is sum_s p[s] - of the same fp16-rounded p as the numerator;
 //   * blockIdx is remapped so that all query blocks of one (b, h) run on one XCD: its K / V (L*d*4 bytes) is fetched
 //     from HBM once and then served by that XCD's L2.
 // Bound: MFMA (arithmetic intensity 4*L*L*C / 8*L*C = L/2 FLOP/B); head dim 40 pads to 48 (QK^T) and 64 (PV).
@@ -24,8 +35,11 @@
 namespace {
 
 typedef short s4_t __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) char lds_char_t;
 
-constexpr int kKV = 64;          // keys per tile
+constexpr int kKV = 64;                          // keys per tile
+constexpr unsigned kOob = 0x80000000u;           // buffer offset beyond any supported tensor: the DMA deposits zeros
+constexpr float kTau = 8.f;                      // lazy rescale threshold (log2 units)
 
 struct SaParams {
     const half_t* q; const half_t* k; const half_t* v; half_t* out;
@@ -33,42 +47,43 @@ struct SaParams {
     int nqb, xcd_map;
     float scale_log2e;
     long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
+    unsigned k_bytes, v_bytes;   // extent of one (b, h) slice of K / V: ((S - 1) * row stride + d) * 2
     unsigned long long* stamps;
 };
 
 template <int NK>
 struct SaCfg {
     static constexpr int DM = (NK + 1) / 2;
-    static constexpr int KP = 16 * NK + 8;                  // K row stride (halves): odd multiple of 16 B
-    static constexpr int VP = (DM <= 3) ? 96 : 160;         // V row stride: (VP/2) % 64 in {16, 48} -> tr reads conflict-free
-    static constexpr int TILE_HALVES = kKV * KP + kKV * VP; // one (K, V) buffer
+    static constexpr bool ONES = (NK & 1) != 0;             // the last 32-channel PV tile has 16 spare channels at 16 NK
+    static constexpr int KC = 2 * NK + 1;                   // 16-byte chunks per K row: 2 NK operand chunks + 1 (odd stride:
+                                                            // the 16 rows of a ds_read_b128 lane group hit 16 distinct banks x4)
+    static constexpr int VC = 2 * NK;                       // chunks per V row
+    static constexpr int KP = 8 * KC, VP = 8 * VC;          // row strides (halves)
+    static constexpr int K_BYTES = kKV * KP * 2, V_BYTES = kKV * VP * 2;
+    static constexpr int TILE_BYTES = K_BYTES + V_BYTES;    // one (K, V) buffer
+    static constexpr int ONES_BYTES = ONES ? kKV * VP * 2 : 0;
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES + ONES_BYTES;
 };
 
-// Prefetch load that hipcc's s_waitcnt insertion does not see (cdna_hip_programming.md section 5.7 form (ii)): the compiler
-// otherwise waits vmcnt(0) before the FIRST MFMA after the loads - exposing the full memory latency every tile - because
-// it reuses the loads' address registers.  The matching wait is stage_wait() right before the LDS write.
-__device__ __forceinline__ void hidden_load(h8_t& dst, const half_t* src) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
-}
-
-// one v_max3_f32; fmaxf() costs a canonicalising v_max_f32 per input on top of the max itself (53 + 8 instructions per
-// tile instead of 16) and the kernel is VALU-issue bound.  Scores are finite or -inf, never NaN.
 __device__ __forceinline__ float max3(float a, float b, float c) {
+    // one v_max3_f32; fmaxf() costs a canonicalising v_max_f32 per input.  Scores are finite or -inf, never NaN.
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 
-__device__ __forceinline__ h4_t tr_read(const half_t* p) {
-    const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (s4_t __attribute__((address_space(3)))*)(const_cast<half_t*>(p)));
+__device__ __forceinline__ h8_t lds_read_h8(unsigned byte_addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) h8_t*>((uintptr_t)byte_addr);
+}
+__device__ __forceinline__ h4_t lds_read_tr(unsigned byte_addr) {
+    const s4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4_t __attribute__((address_space(3)))*)(uintptr_t)byte_addr);
     return __builtin_bit_cast(h4_t, r);
 }
+// LDS-DMA of 16 bytes per lane through a buffer descriptor; the 64 lanes' chunks land at lds_byte + 16 * lane
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, unsigned lds_byte) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, soff, 0, 0);
+}
 
-// QT query tiles (32 rows each) per wave share every K fragment read and every V^T transposed read.
-// ONES (NK odd: the PV row tile has >= 16 padding channels): V's first padding column holds 1.0, so the PV MFMA
-// returns sum_s p[s] in output channel 16*NK for free - no per-score adds, and the sum uses the same fp16-rounded p as
-// the numerator.
 unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cycle sums of workgroup 0 / wave 0
 
 #define SA_STAMP(slot)                                                                          \
@@ -80,18 +95,18 @@ unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cyc
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
 
-// Head dims <= 80: ask for two waves per SIMD (256 registers per wave).  Without the second launch-bound the compiler
-// parks the S / O accumulators in AGPRs and moves them to VGPRs and back for the softmax and the rescale:
-// 191 of the 277 VALU instructions per tile were v_accvgpr_read/write (rocprofv3 PMC: the kernel is VALU-issue bound).
-template <int NK, int WAVES, int QT>
-__global__ __launch_bounds__(64 * WAVES, (NK <= 5 && QT == 1 && WAVES >= 2 ? 2 : 1)) void self_attn_fwd(SaParams p) {   // HIP: 2nd = min waves per SIMD
+// MINW = minimum waves per SIMD the register allocation must allow (HIP's second launch bound).  With it the compiler
+// keeps the S / O accumulators in VGPRs; without it it parks them in AGPRs and copies them back and forth for the softmax.
+template <int NK, int WAVES, int MINW>
+__global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
     using C = SaCfg<NK>;
-    constexpr int T = 64 * WAVES, DM = C::DM, KP = C::KP, VP = C::VP;
-    constexpr int CH = (kKV * 2 * NK + T - 1) / T;          // 16-byte chunks per thread per operand per tile
-    constexpr bool ONES = (NK & 1) != 0;
-    constexpr float kTau = 8.f;                              // lazy rescale: p <= 2^8, exact enough in fp16 / fp32 sums
+    constexpr int DM = C::DM, KP = C::KP, VP = C::VP, KC = C::KC, VC = C::VC;
+    constexpr bool ONES = C::ONES;
+    constexpr int KPW = (KC + WAVES - 1) / WAVES, VPW = (VC + WAVES - 1) / WAVES;   // DMA pieces per wave and tile
+    constexpr bool HOIST = NK <= 5;                          // all LDS reads of a tile issued before its first MFMA
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* lds = reinterpret_cast<half_t*>(smem);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char_t*)smem;
+    const unsigned ones0 = lds0 + 2 * C::TILE_BYTES;
 
     int bh, qb;
     {
@@ -101,124 +116,130 @@ __global__ __launch_bounds__(64 * WAVES, (NK <= 5 && QT == 1 && WAVES >= 2 ? 2 :
     }
     const int b = bh / p.H, h = bh % p.H;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-    const int q0 = (qb * WAVES + wave) * 32 * QT;
+    const int q0 = (qb * WAVES + wave) * 32;
     const int d8 = p.d >> 3;
-    const half_t* kg = p.k + b * p.ksb + h * p.ksh;
-    const half_t* vg = p.v + b * p.vsb + h * p.vsh;
+    const int ntiles = (p.S + kKV - 1) / kKV;
 
-    // one-time LDS constants of both buffers: zero K pad columns [d, 16*NK); V ones column 16*NK (ONES)
-    if (16 * NK > p.d) {
-        const int padc = 16 * NK - p.d;
-        for (int idx = threadIdx.x; idx < 2 * kKV * padc; idx += T) {
-            const int buf = idx / (kKV * padc), rem = idx % (kKV * padc);
-            lds[buf * C::TILE_HALVES + (rem / padc) * KP + p.d + rem % padc] = (half_t)0;
+    // ---- DMA plan: piece j of the K image = LDS chunks 64 j .. 64 j + 63 (chunk c of row s sits at s * KC + c); wave w
+    // issues pieces w, w + WAVES, ...; the per-lane source offsets are tile-invariant (the tile advances in the scalar offset)
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(p.k + b * p.ksb + h * p.ksh), 0, p.k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<half_t*>(p.v + b * p.vsb + h * p.vsh), 0, p.v_bytes, 0x00020000);
+    unsigned kvo[KPW], vvo[VPW];
+    int krow[KPW], vrow[VPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int ci = 64 * (wave + i * WAVES) + lane;
+        krow[i] = ci / KC;
+        const int col = ci - krow[i] * KC;
+        kvo[i] = col < d8 ? (unsigned)(krow[i] * (int)p.kss + col * 8) * 2u : kOob;
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+        const int ci = 64 * (wave + i * WAVES) + lane;
+        vrow[i] = ci / VC;
+        const int col = ci - vrow[i] * VC;
+        vvo[i] = col < d8 ? (unsigned)(vrow[i] * (int)p.vss + col * 8) * 2u : kOob;
+    }
+    const unsigned ktile = (unsigned)(kKV * p.kss * 2), vtile = (unsigned)(kKV * p.vss * 2);
+    auto stage = [&](int tile, int buf) {
+        const unsigned kb = lds0 + buf * C::TILE_BYTES, vb = kb + C::K_BYTES;
+        if ((tile + 1) * kKV <= p.S) {                       // wave-uniform: a full tile
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int j = wave + i * WAVES;
+                if (j < KC) dma16(krs, kvo[i], tile * ktile, kb + j * 1024);          // j < KC: wave-uniform
+            }
+#pragma unroll
+            for (int i = 0; i < VPW; ++i) {
+                const int j = wave + i * WAVES;
+                if (j < VC) dma16(vrs, vvo[i], tile * vtile, vb + j * 1024);
+            }
+        } else {                                             // the ragged last tile: keys >= S are fetched as zeros
+#pragma unroll
+            for (int i = 0; i < KPW; ++i) {
+                const int j = wave + i * WAVES;
+                if (j < KC) dma16(krs, tile * kKV + krow[i] < p.S ? kvo[i] : kOob, tile * ktile, kb + j * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < VPW; ++i) {
+                const int j = wave + i * WAVES;
+                if (j < VC) dma16(vrs, tile * kKV + vrow[i] < p.S ? vvo[i] : kOob, tile * vtile, vb + j * 1024);
+            }
+        }
+    };
+    stage(0, 0);
+
+    // ---- constant LDS region of the row-sum trick: rows of VP halves, [row][0] = 1, [row][1..15] = 0 (the rest is never read)
+    if (ONES) {
+        for (int idx = threadIdx.x; idx < kKV * 2; idx += 64 * WAVES) {
+            const h8_t one = {(half_t)1, 0, 0, 0, 0, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<__attribute__((address_space(3))) h8_t*>((uintptr_t)(ones0 + (idx >> 1) * VP * 2 + (idx & 1) * 16)) =
+                (idx & 1) ? zero : one;
         }
     }
-    if (ONES) {
-        for (int idx = threadIdx.x; idx < 2 * kKV; idx += T)
-            lds[(idx / kKV) * C::TILE_HALVES + kKV * KP + (idx % kKV) * VP + 16 * NK] = (half_t)1;
-    }
 
-    // Q^T fragments stay in registers: qf[qt][ks] = Q[q0 + 32 qt + r][16 ks + 8 hh .. +8]
-    h8_t qf[QT][NK];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int row = min(q0 + 32 * qt + r, p.L - 1);
+    // ---- Q^T fragments stay in registers, pre-multiplied by scale * log2(e): qf[ks] = Q[q0 + r][16 ks + 8 hh .. +8]
+    h8_t qf[NK];
+    {
+        const int row = min(q0 + r, p.L - 1);
         const half_t* qp = p.q + b * p.qsb + h * p.qsh + (long long)row * p.qsl;
+        const float c2 = p.scale_log2e;
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             const int col = 16 * ks + 8 * hh;
             h8_t val = {0, 0, 0, 0, 0, 0, 0, 0};
             if (col < p.d) val = *reinterpret_cast<const h8_t*>(qp + col);
-            qf[qt][ks] = val;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (half_t)((float)val[j] * c2);
+            qf[ks] = val;
         }
     }
 
-    h8_t kst[CH], vst[CH];                                   // staging registers for the next tile
-    // per-thread staging geometry, fixed for the whole kernel: chunk c of this thread is row srow[c], 16-byte column scol[c]
-    int srow[CH], scol[CH];
-    const half_t* kptr[CH];
-    const half_t* vptr[CH];
+    f16x_t o[DM], negm;                                      // negm: -(running max) of this lane's query row, 16 copies
+    float l_run = 0.f;
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-        const int idx = threadIdx.x + c * T;
-        srow[c] = idx / d8;
-        scol[c] = idx - srow[c] * d8;
-        kptr[c] = kg + (long long)srow[c] * p.kss + scol[c] * 8;
-        vptr[c] = vg + (long long)srow[c] * p.vss + scol[c] * 8;
-    }
-    const long long ktile = (long long)kKV * p.kss, vtile = (long long)kKV * p.vss;
-    auto stage_load = [&](int tile) {
-        const bool ragged = (tile + 1) * kKV > p.S;              // wave-uniform: only the last tile can run past S
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (srow[c] < kKV) {
-                long long ko = (long long)tile * ktile, vo = (long long)tile * vtile;
-                if (ragged) {                                    // clamp the row to the last valid key (masked in the softmax)
-                    const int back = max(tile * kKV + srow[c] - (p.S - 1), 0);
-                    ko -= (long long)back * p.kss;
-                    vo -= (long long)back * p.vss;
-                }
-                hidden_load(kst[c], kptr[c] + ko);
-                hidden_load(vst[c], vptr[c] + vo);
-            }
-        }
-    };
-    auto stage_write = [&](int buf) {
-        half_t* Kb = lds + buf * C::TILE_HALVES;
-        half_t* Vb = Kb + kKV * KP;
+    for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
-        for (int c = 0; c < CH; ++c)                             // the hidden loads have landed: name every destination
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kst[c]), "+v"(vst[c]) :: "memory");
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (srow[c] < kKV) {
-                *reinterpret_cast<h8_t*>(Kb + srow[c] * KP + scol[c] * 8) = kst[c];
-                *reinterpret_cast<h8_t*>(Vb + srow[c] * VP + scol[c] * 8) = vst[c];
-            }
-        }
-    };
+        for (int i = 0; i < 16; ++i) o[dm][i] = 0.f;
 
-    f16x_t o[QT][DM];
-    float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        m_run[qt] = -INFINITY;
-        l_run[qt] = 0.f;
-#pragma unroll
-        for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[qt][dm][i] = 0.f;
-    }
+    // per-lane parts of the LDS read addresses (bytes), relative to a buffer's K / V image
+    const unsigned k_lane = (unsigned)(r * KP + 8 * hh) * 2u;
+    const int g = (lane >> 4) & 1;
+    const unsigned v_lane = (unsigned)((4 * hh + ((lane & 15) >> 2)) * VP + 16 * g + 4 * (lane & 3)) * 2u;
+    // last channel tile: the g = 1 lanes (channels 16 NK ..) read the constant region; its address is biased so that the
+    // tile's common immediate (32 (DM-1) halves) lands on column 0
+    const unsigned ones_lane = ones0 + (unsigned)((4 * hh + ((lane & 15) >> 2)) * VP + 4 * (lane & 3)) * 2u - 64u * (DM - 1);
 
-    const int ntiles = (p.S + kKV - 1) / kKV;
-    stage_load(0);
-    stage_write(0);
-    __syncthreads();
-
-    // per-lane constant part of the transposed-read address: row (4 hh + (i >> 2)), column 16 * ((lane >> 4) & 1) + 4 * (i & 3)
-    const int tr_off = (4 * hh + ((lane & 15) >> 2)) * VP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const float c2 = p.scale_log2e;
     const bool dbg = p.stamps != nullptr && blockIdx.x == 0 && wave == 0;
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < ntiles) stage_load(t + 1);               // in flight during this tile's MFMAs
+        // tile t: this wave's pieces have landed (the only DMAs outstanding), then everyone's - and every wave is done
+        // reading buffer buf ^ 1 (tile t-1), so tile t+1 may go there
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // The compiler puts an `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows an LDS-DMA it has
+        // seen (it cannot tell the transposed read from the DMA's destination).  HOIST kernels therefore issue ALL LDS reads
+        // of tile t first and the DMA of tile t+1 behind them; the others issue the DMA here and pay part of its latency
+        // at their first transposed read.
+        if (!HOIST && t + 1 < ntiles) stage(t + 1, buf ^ 1);
         SA_STAMP(0)
-        const half_t* Kb = lds + buf * C::TILE_HALVES;
-        const half_t* Vb = Kb + kKV * KP;
+        const unsigned kb = lds0 + buf * C::TILE_BYTES + k_lane;
+        const unsigned vb = lds0 + buf * C::TILE_BYTES + C::K_BYTES + v_lane;
+        const unsigned vb_last = (ONES && g == 1) ? ones_lane : vb;
 
-        // ---- HOIST (head dims <= 64, where the registers allow it): all LDS reads of the tile go out first - a read
-        // issued right before its MFMA exposes the LDS latency at 1-2 waves per SIMD - K fragments for QK^T, then the
-        // V^T fragments, whose latency the QK^T MFMAs and the softmax cover
-        constexpr bool HOIST = NK <= 4;
-        auto k_frag = [&](int m, int ks) { return *reinterpret_cast<const h8_t*>(Kb + (32 * m + r) * KP + 16 * ks + 8 * hh); };
+        auto k_frag = [&](int m, int ks) { return lds_read_h8(kb + (32 * m * KP + 16 * ks) * 2); };
         auto v_frag = [&](int dm, int tt) {
-            const half_t* vp = Vb + tr_off + (16 * tt) * VP + 32 * dm;
-            const h4_t lo = tr_read(vp);
-            const h4_t hi = tr_read(vp + 8 * VP);
+            const unsigned a = ((ONES && dm == DM - 1) ? vb_last : vb) + (16 * tt * VP + 32 * dm) * 2;
+            const h4_t lo = lds_read_tr(a);
+            const h4_t hi = lds_read_tr(a + 8 * VP * 2);
             return h8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
         h8_t kf[HOIST ? 2 : 1][HOIST ? NK : 1];
@@ -233,137 +254,123 @@ __global__ __launch_bounds__(64 * WAVES, (NK <= 5 && QT == 1 && WAVES >= 2 ? 2 :
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
             __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < ntiles) stage(t + 1, buf ^ 1);       // in flight during this tile's MFMAs and softmax
+            __builtin_amdgcn_sched_barrier(0);
         }
 
-        // ---- S^T = K . Q^T  (2 row tiles of 32 keys); each K fragment feeds the QT query tiles
-        f16x_t s[QT][2];
+        // ---- S'^T = K . Q'^T - m  (2 row tiles of 32 keys): the chain starts from negm
+        f16x_t s[2];
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[qt][m][i] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
             for (int ks = 0; ks < NK; ++ks) {
                 const h8_t kfr = HOIST ? kf[HOIST ? m : 0][HOIST ? ks : 0] : k_frag(m, ks);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) s[qt][m] = mfma_32x32x16(kfr, qf[qt][ks], s[qt][m]);
+                s[m] = mfma_32x32x16(kfr, qf[ks], ks == 0 ? negm : s[m]);
             }
-
-        if (dbg) asm volatile("" :: "v"(s[0][0][0]), "v"(s[0][1][15]));
-        SA_STAMP(1)
-        // ---- online softmax, base 2, lazy rescale.  Element i of s[qt][m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh.
-        const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
-        h8_t pf[QT][4];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            if (kv_left < kKV) {                             // wave-uniform: only the ragged last tile masks
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh >= kv_left) s[qt][m][i] = -INFINITY;
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) mx = max3(mx, s[qt][m][i], s[qt][m][i + 1]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;     // c2 > 0: max commutes with the scaling
-            if (__any(mx > m_run[qt] + kTau)) {              // wave-uniform: some row's max grew by more than 2^tau
-                const float m_new = fmaxf(m_run[qt], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-                m_run[qt] = m_new;
-                l_run[qt] *= alpha;
-#pragma unroll
-                for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[qt][dm][i] *= alpha;
-            }
-            const float nm = -m_run[qt];
-            float psum = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][m][i], c2, nm));
-                    if (!ONES) psum += e;
-                    s[qt][m][i] = e;
-                }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) pf[qt][2 * m + (i >> 3)][i & 7] = (half_t)s[qt][m][i];
-            if (!ONES) l_run[qt] += psum;
         }
+        if (dbg) asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
+        SA_STAMP(1)
 
+        // ---- softmax, base 2.  Element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this lane's query row.
+        const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
+        if (kv_left < kKV) {                                 // wave-uniform: only the ragged last tile masks
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh >= kv_left) s[m][i] = -INFINITY;
+        }
+        float mxa = max3(s[0][0], s[0][1], s[0][2]), mxb = max3(s[1][0], s[1][1], s[1][2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) { mxa = max3(mxa, s[0][i], s[0][i + 1]); mxb = max3(mxb, s[1][i], s[1][i + 1]); }
+        float mx = max3(mxa, mxb, s[0][15]);
+        mx = max3(mx, s[1][15], s[1][15]);
+        if (t == 0 || __any(mx > kTau)) {                    // wave-uniform and rare after the first tiles
+            // the row's maximum over all 64 keys (the other half of the keys lives in lane ^ 32)
+            const float mrow = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float delta = t == 0 ? mrow : fmaxf(mrow, 0.f);          // the running max only grows
+            const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) negm[i] -= delta;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[m][i] -= delta;
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;
+        }
+        h8_t pf[4];
+        float psum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(s[m][i]), e1 = __builtin_amdgcn_exp2f(s[m][i + 1]);
+                if (!ONES) psum += e0 + e1;
+                const h2_t pk = __builtin_convertvector(f2x_t{e0, e1}, h2_t);          // v_cvt_pk_f16_f32
+                pf[2 * m + (i >> 3)][i & 7] = pk[0];
+                pf[2 * m + (i >> 3)][(i & 7) + 1] = pk[1];
+            }
+        if (!ONES) l_run += psum;
         SA_STAMP(2)
-        // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels); V^T fragments shared by the QT tiles
+
+        // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels)
 #pragma unroll
         for (int dm = 0; dm < DM; ++dm) {
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const h8_t vfr = HOIST ? vf[HOIST ? dm : 0][HOIST ? tt : 0] : v_frag(dm, tt);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) o[qt][dm] = mfma_32x32x16(vfr, pf[qt][tt], o[qt][dm]);
+                o[dm] = mfma_32x32x16(vfr, pf[tt], o[dm]);
             }
         }
-        if (dbg) asm volatile("" :: "v"(o[0][0][0]), "v"(o[0][DM - 1][15]));
+        if (dbg) asm volatile("" :: "v"(o[0][0]), "v"(o[DM - 1][15]));
         SA_STAMP(3)
-        if (t + 1 < ntiles) stage_write(buf ^ 1);            // buffer buf^1 was last read in iteration t-1
-        SA_STAMP(4)
-        __syncthreads();
-        SA_STAMP(5)
     }
     if (dbg && lane == 0)
         for (int i = 0; i < 6; ++i) p.stamps[i] = seg[i];
 
     // ---- epilogue: O / l, fp16, out[b, q, h, :]
+    float l_tot;
+    if (ONES) {
+        // channel 16 NK of O^T is sum_s p: row tile DM-1, element 8 of the hh = 0 lanes (16 = (i & 3) + 8 (i >> 2) + 4 hh)
+        l_tot = __shfl(o[DM - 1][8], r, 64);                 // lane r (hh = 0) holds it for query row r
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    }
+    const float inv = 1.f / l_tot;
+    const int qrow = q0 + r;
+    if (qrow < p.L) {
+        half_t* op = p.out + b * p.osb + h * p.osh + (long long)qrow * p.osl;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        float l_tot;
-        if (ONES) {
-            // channel 16*NK of O^T is sum_s p: row tile DM-1, element 8 * ((16 NK - 32 (DM-1)) >> 3) of the hh = 0 lanes
-            constexpr int kIdx = 4 * ((16 * NK - 32 * (DM - 1)) >> 3);
-            const float mine = o[qt][DM - 1][kIdx];
-            l_tot = __shfl(mine, r, 64);                     // lane r (hh = 0) holds it for query row r
-        } else {
-            l_tot = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);
-        }
-        const float inv = 1.f / l_tot;
-        const int qrow = q0 + 32 * qt + r;
-        if (qrow < p.L) {
-            half_t* op = p.out + b * p.osb + h * p.osh + (long long)qrow * p.osl;
+        for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
-            for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
-                    if (dd0 < p.d) {
-                        const h4_t ov = {(half_t)(o[qt][dm][4 * g4] * inv), (half_t)(o[qt][dm][4 * g4 + 1] * inv),
-                                         (half_t)(o[qt][dm][4 * g4 + 2] * inv), (half_t)(o[qt][dm][4 * g4 + 3] * inv)};
-                        *reinterpret_cast<h4_t*>(op + dd0) = ov;
-                    }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                if (dd0 < p.d) {
+                    const h4_t ov = {(half_t)(o[dm][4 * g4] * inv), (half_t)(o[dm][4 * g4 + 1] * inv),
+                                     (half_t)(o[dm][4 * g4 + 2] * inv), (half_t)(o[dm][4 * g4 + 3] * inv)};
+                    *reinterpret_cast<h4_t*>(op + dd0) = ov;
                 }
-        }
+            }
     }
 }
 
-template <int NK, int WAVES, int QT>
+template <int NK, int WAVES, int MINW>
 int launch(const SaParams& p0, hipStream_t st) {
     SaParams p = p0;
-    p.nqb = (p.L + 32 * QT * WAVES - 1) / (32 * QT * WAVES);
+    p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
     p.xcd_map = ((p.Bc * p.H) % 8 == 0) ? 1 : 0;
-    const size_t lds = (size_t)2 * SaCfg<NK>::TILE_HALVES * sizeof(half_t);
+    const size_t lds = (size_t)SaCfg<NK>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, QT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, MINW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    DSC_LAUNCH((self_attn_fwd<NK, WAVES, QT>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
+    DSC_LAUNCH((self_attn_fwd<NK, WAVES, MINW>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
@@ -371,21 +378,20 @@ int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant
 
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
-    // enough workgroups to fill 256 CUs: 4 waves (128 query rows) per workgroup when that still gives >= 256 of them
-    const long long wg4 = (long long)p.Bc * p.H * ((p.L + 127) / 128);
-    if (NK <= 4) {
-        const long long wg4x2 = (long long)p.Bc * p.H * ((p.L + 255) / 256);
-        (void)wg4x2;    // measured: two query tiles per wave lose to one (220+ VGPRs -> 1 wave/SIMD): tuning variant only
-        if (g_sa_variant == 2) return launch<NK, 4, (NK <= 4 ? 2 : 1)>(p, st);
-    }
-    // 8 waves (256 query rows share each K/V tile: half the L2->LDS traffic per MFMA) once that still leaves >= 2
-    // workgroups per CU: +11 % at Bc = 16, nothing at Bc = 2 (tools/mb_sa.py)
+    constexpr int MW = NK <= 5 ? 2 : 1;                       // waves per SIMD the registers allow: 256 / 512 per wave
+    // variant 3: three waves per SIMD (168 registers) - the configuration that FAULTED with register-staged tiles; kept
+    // reachable so that the tests can run it on the LDS-DMA staging
+    if (g_sa_variant == 3 && NK <= 4) return launch<(NK <= 4 ? NK : 3), 4, 3>(p, st);
+    // 8 waves (256 query rows share each K/V tile: half the DMA pieces and L2->LDS bytes per MFMA) once that still leaves
+    // >= 2 workgroups per CU
     const long long wg8 = (long long)p.Bc * p.H * ((p.L + 255) / 256);
-    if (NK <= 5 && ((g_sa_variant == 0 && wg8 >= 512) || g_sa_variant == 3)) return launch<(NK <= 5 ? NK : 3), 8, 1>(p, st);
-    if (wg4 >= 256 || g_sa_variant == 1) return launch<NK, 4, 1>(p, st);
+    if (NK <= 5 && ((g_sa_variant == 0 && wg8 >= 512) || g_sa_variant == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
+    // 4 waves (128 query rows) per workgroup when that gives >= 256 of them
+    const long long wg4 = (long long)p.Bc * p.H * ((p.L + 127) / 128);
+    if (wg4 >= 256 || g_sa_variant == 1) return launch<NK, 4, MW>(p, st);
     const long long wg2 = (long long)p.Bc * p.H * ((p.L + 63) / 64);
-    if (wg2 >= 128 || NK >= 6) return launch<NK, 2, 1>(p, st);   // one wave alone would need 160 staging registers at d = 160
-    return launch<NK, (NK >= 6 ? 2 : 1), 1>(p, st);
+    if (wg2 >= 128 || NK >= 6) return launch<NK, 2, MW>(p, st);
+    return launch<NK, 1, MW>(p, st);
 }
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -406,6 +412,13 @@ extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, vo
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7) ||
         !strides_ok(q_strides) || !strides_ok(k_strides) || !strides_ok(v_strides) || !strides_ok(o_strides))
         return DSC_ERR_UNSUPPORTED;
+    // the K / V tiles are addressed through 32-bit buffer offsets: key-row strides must be positive and one (b, h) slice
+    // must stay below 2 GiB (an SD / SDXL slice is a few MB)
+    if (k_strides[1] <= 0 || v_strides[1] <= 0) return DSC_ERR_UNSUPPORTED;
+    const long long kext = ((long long)(S - 1) * k_strides[1] + d) * 2, vext = ((long long)(S - 1) * v_strides[1] + d) * 2;
+    const long long kreach = ((long long)((S + kKV - 1) / kKV) * kKV * k_strides[1] + d) * 2;
+    const long long vreach = ((long long)((S + kKV - 1) / kKV) * kKV * v_strides[1] + d) * 2;
+    if (kext >= (1ll << 31) || vext >= (1ll << 31) || kreach >= (1ll << 31) || vreach >= (1ll << 31)) return DSC_ERR_UNSUPPORTED;
     SaParams p{};
     p.q = static_cast<const half_t*>(q); p.k = static_cast<const half_t*>(k);
     p.v = static_cast<const half_t*>(v); p.out = static_cast<half_t*>(out);
@@ -415,8 +428,11 @@ extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, vo
     p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
     p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
     p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
+    p.k_bytes = (unsigned)kext; p.v_bytes = (unsigned)vext;
     p.stamps = g_sa_stamps;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d <= 16) return launch_nk<1>(p, st);
+    if (d <= 32) return launch_nk<2>(p, st);
     if (d <= 48) return launch_nk<3>(p, st);
     if (d <= 64) return launch_nk<4>(p, st);
     if (d <= 80) return launch_nk<5>(p, st);

@@ -41,6 +41,34 @@ def test_code_object_is_gfx950_only():
     assert targets == {b"gfx950"}, targets
 
 
+def test_self_attention_kernel_has_no_hidden_register_loads():
+    """The flash self-attention kernel stages K / V by LDS-DMA: no inline-asm load with a register destination (the
+    construct whose result the compiler could move or spill before it landed - the cause of the round-1 fault at three
+    waves per SIMD), and no instantiation of it spills or uses scratch (checked on the built code object's metadata)."""
+    import os
+    import re
+    import subprocess
+    src = open(os.path.join(os.path.dirname(dsc.lib_path()), "csrc", "self_attn.hip")).read()
+    for stmt in re.findall(r"asm\s*(?:volatile)?\s*\((.*?)\);", src, flags=re.S):
+        assert not re.search(r"(global|buffer|flat|ds)_(load|read)", stmt), stmt      # only waits / v_max3 remain in asm
+    assert "raw_ptr_buffer_load_lds" in src
+    import tempfile
+    root = os.path.dirname(os.path.dirname(dsc.lib_path()))
+    with tempfile.TemporaryDirectory() as tmp:                   # device-only compile of the same source with the build's flags
+        work = os.path.join(tmp, "self_attn.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only",
+                               "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "diffusionspatialcontrol_amd", "csrc"),
+                               "-S", os.path.join(root, "diffusionspatialcontrol_amd", "csrc", "self_attn.hip"), "-o", work],
+                              stderr=subprocess.DEVNULL)
+        notes = open(work).read()
+        notes = notes[notes.index("amdhsa.kernels:"):]              # the code object's metadata (YAML) at the end of the listing
+    kernels = re.findall(r"\.name:\s+(\S*self_attn_fwd\S*)(.*?)\.wavefront_size", notes, flags=re.S)
+    assert len(kernels) >= 20
+    for name, body in kernels:
+        assert re.search(r"\.private_segment_fixed_size:\s+0\b", body), name
+        assert re.search(r"\.vgpr_spill_count:\s+0\b", body), name
+
+
 def test_argument_validation_needs_no_gpu(lib):
     s3 = (ctypes.c_int64 * 3)(8 * 64 * 40, 320, 40)
     dummy = ctypes.c_void_p(0x1000)

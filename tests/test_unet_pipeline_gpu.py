@@ -134,6 +134,32 @@ def test_self_attention(ops, B, H, L, d):
         assert (out2.float().cpu() - ref2).abs().max().item() < 3e-3
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("B,H,L,d", [(2, 8, 4096, 40), (2, 10, 1000, 64), (1, 8, 520, 80), (2, 4, 300, 32)])
+def test_self_attention_tiling_variants(ops, variant, B, H, L, d):
+    """every tiling of the flash kernel, forced through dsc_debug_set_self_attn_variant: 1 = 4 waves per workgroup, 2 = 8 waves
+    (two per SIMD from ONE workgroup), 3 = 4 waves with a three-waves-per-SIMD register budget - the configuration that
+    faulted in round 1, when the K / V tiles were staged through registers the compiler could not see being written; the
+    tiles now arrive by LDS-DMA.  Same fp32 SDPA reference and tolerance as test_self_attention, incl. the rescale branch."""
+    from diffusionspatialcontrol_amd import _lib
+    lib = _lib.load_library()
+    if variant == 3 and d > 64:
+        pytest.skip("three waves per SIMD: head dims <= 64 only")
+    g = torch.Generator().manual_seed(L * d + H + variant)
+    q, k, v = (torch.randn(B, L, H, d, generator=g).half() for _ in range(3))
+    k[:, L - 7] = q[:, 5] * 4.0                       # a late spike: the running max moves near the end of the sweep
+    ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2)
+    lib.dsc_debug_set_self_attn_variant(variant)
+    try:
+        out = ops.self_attention(q.cuda(), k.cuda(), v.cuda())
+        again = ops.self_attention(q.cuda(), k.cuda(), v.cuda())
+    finally:
+        lib.dsc_debug_set_self_attn_variant(0)
+    err = (out.float().cpu() - ref).abs()
+    assert err.max().item() < 3e-3 and err.mean().item() < 2e-4, (err.max().item(), err.mean().item())
+    assert torch.equal(out, again)
+
+
 @pytest.mark.parametrize("B,H,L,S,d", [(2, 8, 4096, 257, 40), (2, 8, 256, 257, 160), (1, 8, 1024, 77, 80), (2, 5, 64, 300, 64)])
 def test_attention_keys_differ_from_queries(ops, B, H, L, S, d):
     """dsc_self_attn_fwd with S != L (a ragged last key tile): the IP-Adapter image-token attention of the 257-token variants"""

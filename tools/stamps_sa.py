@@ -5,7 +5,7 @@ import torch
 from diffusionspatialcontrol_amd import ops, _lib
 lib = _lib.load_library(); dev = "cuda"
 buf = torch.zeros(8, dtype=torch.int64, device=dev)
-names = ["issue prefetch loads", "QK^T (6 MFMA + 6 ds_read)", "softmax", "PV (8 MFMA + 16 tr reads)", "wait + LDS write", "barrier"]
+names = ["wait + barrier", "LDS reads + DMA issue + QK^T", "softmax", "PV", "-", "-"]
 for (B, H, L, d) in [(2, 8, 4096, 40), (2, 8, 1024, 80)]:
     qkv = torch.randn(B, L, 3 * H * d, device=dev).half(); C = H * d
     q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
