@@ -51,18 +51,24 @@ struct SaParams {
     unsigned long long* stamps;
 };
 
-template <int NK>
+// D8 = 0: generic image - K rows of 2 NK + 1 chunks (2 NK operand chunks, zero beyond the head dim, + 1 chunk that makes the
+// row stride an odd number of 16 B: the 16 rows of a ds_read_b128 lane group then hit 16 distinct 4-bank groups), V rows of
+// 2 NK chunks.  D8 > 0 (= d / 8, odd): COMPACT image for exactly that head dim - rows of d8 chunks, no padding at all: an odd
+// chunk count is conflict-free by itself, the K operand's columns d .. 16 NK - 1 then read the next row's first halves, which
+// only ever multiply Q's zero padding, and the V operand's read the next row too, which only reaches output channels >= d that
+// are never stored.  d = 40: 10 DMA pieces per tile instead of 13.
+template <int NK, int D8>
 struct SaCfg {
     static constexpr int DM = (NK + 1) / 2;
     static constexpr bool ONES = (NK & 1) != 0;             // the last 32-channel PV tile has 16 spare channels at 16 NK
-    static constexpr int KC = 2 * NK + 1;                   // 16-byte chunks per K row: 2 NK operand chunks + 1 (odd stride:
-                                                            // the 16 rows of a ds_read_b128 lane group hit 16 distinct banks x4)
-    static constexpr int VC = 2 * NK;                       // chunks per V row
+    static constexpr int KC = D8 ? D8 : 2 * NK + 1;         // 16-byte chunks per K row
+    static constexpr int VC = D8 ? D8 : 2 * NK;             // chunks per V row
     static constexpr int KP = 8 * KC, VP = 8 * VC;          // row strides (halves)
     static constexpr int K_BYTES = kKV * KP * 2, V_BYTES = kKV * VP * 2;
     static constexpr int TILE_BYTES = K_BYTES + V_BYTES;    // one (K, V) buffer
-    static constexpr int ONES_BYTES = ONES ? kKV * VP * 2 : 0;
-    static constexpr int LDS_BYTES = 2 * TILE_BYTES + ONES_BYTES;
+    static constexpr int ONES_BYTES = ONES ? kKV * VP * 2 + 64 : 0;
+    static constexpr int LDS_BYTES = 2 * TILE_BYTES + ONES_BYTES + 64;       // + slack for the compact image's over-reads
+    static_assert(D8 == 0 || ((D8 & 1) && D8 > 2 * NK - 2 && D8 <= 2 * NK), "compact rows: odd d/8 that needs exactly NK k-steps");
 };
 
 __device__ __forceinline__ float max3(float a, float b, float c) {
@@ -97,13 +103,24 @@ unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cyc
 
 // MINW = minimum waves per SIMD the register allocation must allow (HIP's second launch bound).  With it the compiler
 // keeps the S / O accumulators in VGPRs; without it it parks them in AGPRs and copies them back and forth for the softmax.
-template <int NK, int WAVES, int MINW>
-__global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
-    using C = SaCfg<NK>;
+//
+// NLOAD > 0: the workgroup has NLOAD waves more than WAVES, and those do nothing but the LDS-DMA of the K / V tiles (one
+// `buffer_load ... lds` per 1-KiB piece; a wave gets ~one piece per 100-200 cycles through: 13 of them cost each of 4 computing
+// waves ~450 of ~1900 cycles per tile when they issued their share themselves).  The computing waves then contain no vector
+// memory instruction between their Q loads and their output stores; all WAVES + NLOAD waves meet at ONE s_barrier per tile.
+template <int NK, int WAVES, int MINW, int D8, int NLOAD>
+__global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaParams p) {
+    constexpr bool LOADER = NLOAD > 0;
+    using C = SaCfg<NK, D8>;
     constexpr int DM = C::DM, KP = C::KP, VP = C::VP, KC = C::KC, VC = C::VC;
     constexpr bool ONES = C::ONES;
-    constexpr int KPW = (KC + WAVES - 1) / WAVES, VPW = (VC + WAVES - 1) / WAVES;   // DMA pieces per wave and tile
+    constexpr int NISSUE = LOADER ? NLOAD : WAVES;           // waves that issue DMA
+    constexpr int KPW = (KC + NISSUE - 1) / NISSUE, VPW = (VC + NISSUE - 1) / NISSUE;   // pieces per issuing wave and tile
     constexpr bool HOIST = NK <= 5;                          // all LDS reads of a tile issued before its first MFMA
+    // 168-register kernels (three waves on a SIMD) with loader waves: the V^T fragments are read BEHIND the QK^T MFMAs, into
+    // the registers the K fragments leave (their latency hides under the softmax); nothing orders LDS reads against DMA in
+    // the computing waves of a loader kernel
+    constexpr bool V_LATE = HOIST && LOADER && (MINW >= 3 || WAVES + NLOAD > 8);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char_t*)smem;
     const unsigned ones0 = lds0 + 2 * C::TILE_BYTES;
@@ -120,60 +137,78 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
     const int d8 = p.d >> 3;
     const int ntiles = (p.S + kKV - 1) / kKV;
 
-    // ---- DMA plan: piece j of the K image = LDS chunks 64 j .. 64 j + 63 (chunk c of row s sits at s * KC + c); wave w
-    // issues pieces w, w + WAVES, ...; the per-lane source offsets are tile-invariant (the tile advances in the scalar offset)
+    // ---- DMA plan: piece j of the K image = LDS chunks 64 j .. 64 j + 63 (chunk c of row s sits at s * KC + c).  Without a
+    // loader wave, wave w issues pieces w, w + WAVES, ...; the per-lane source offsets are tile-invariant (the tile advances
+    // in the scalar offset)
+    const bool issues_dma = !LOADER || wave >= WAVES;        // wave-uniform
+    const int j0 = LOADER ? wave - WAVES : wave, jstep = NISSUE;
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<half_t*>(p.k + b * p.ksb + h * p.ksh), 0, p.k_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<half_t*>(p.v + b * p.vsb + h * p.vsh), 0, p.v_bytes, 0x00020000);
     unsigned kvo[KPW], vvo[VPW];
     int krow[KPW], vrow[VPW];
+    if (issues_dma) {
 #pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int ci = 64 * (wave + i * WAVES) + lane;
-        krow[i] = ci / KC;
-        const int col = ci - krow[i] * KC;
-        kvo[i] = col < d8 ? (unsigned)(krow[i] * (int)p.kss + col * 8) * 2u : kOob;
-    }
+        for (int i = 0; i < KPW; ++i) {
+            const int ci = 64 * (j0 + i * jstep) + lane;
+            krow[i] = ci / KC;
+            const int col = ci - krow[i] * KC;
+            kvo[i] = col < d8 ? (unsigned)(krow[i] * (int)p.kss + col * 8) * 2u : kOob;
+        }
 #pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-        const int ci = 64 * (wave + i * WAVES) + lane;
-        vrow[i] = ci / VC;
-        const int col = ci - vrow[i] * VC;
-        vvo[i] = col < d8 ? (unsigned)(vrow[i] * (int)p.vss + col * 8) * 2u : kOob;
+        for (int i = 0; i < VPW; ++i) {
+            const int ci = 64 * (j0 + i * jstep) + lane;
+            vrow[i] = ci / VC;
+            const int col = ci - vrow[i] * VC;
+            vvo[i] = col < d8 ? (unsigned)(vrow[i] * (int)p.vss + col * 8) * 2u : kOob;
+        }
     }
     const unsigned ktile = (unsigned)(kKV * p.kss * 2), vtile = (unsigned)(kKV * p.vss * 2);
-    auto stage = [&](int tile, int buf) {
+    // which = 0: the K image, 1: the V image (issued at two different points of the tile loop)
+    auto stage_part = [&](int tile, int buf, int which) {
         const unsigned kb = lds0 + buf * C::TILE_BYTES, vb = kb + C::K_BYTES;
-        if ((tile + 1) * kKV <= p.S) {                       // wave-uniform: a full tile
+        const bool full = (tile + 1) * kKV <= p.S;           // wave-uniform; the ragged last tile fetches keys >= S as zeros
+        if (which == 0) {
 #pragma unroll
             for (int i = 0; i < KPW; ++i) {
-                const int j = wave + i * WAVES;
-                if (j < KC) dma16(krs, kvo[i], tile * ktile, kb + j * 1024);          // j < KC: wave-uniform
+                const int j = j0 + i * jstep;
+                if (j < KC) {                                // wave-uniform
+                    if (full) dma16(krs, kvo[i], tile * ktile, kb + j * 1024);
+                    else dma16(krs, tile * kKV + krow[i] < p.S ? kvo[i] : kOob, tile * ktile, kb + j * 1024);
+                }
             }
+        } else {
 #pragma unroll
             for (int i = 0; i < VPW; ++i) {
-                const int j = wave + i * WAVES;
-                if (j < VC) dma16(vrs, vvo[i], tile * vtile, vb + j * 1024);
-            }
-        } else {                                             // the ragged last tile: keys >= S are fetched as zeros
-#pragma unroll
-            for (int i = 0; i < KPW; ++i) {
-                const int j = wave + i * WAVES;
-                if (j < KC) dma16(krs, tile * kKV + krow[i] < p.S ? kvo[i] : kOob, tile * ktile, kb + j * 1024);
-            }
-#pragma unroll
-            for (int i = 0; i < VPW; ++i) {
-                const int j = wave + i * WAVES;
-                if (j < VC) dma16(vrs, tile * kKV + vrow[i] < p.S ? vvo[i] : kOob, tile * vtile, vb + j * 1024);
+                const int j = j0 + i * jstep;
+                if (j < VC) {
+                    if (full) dma16(vrs, vvo[i], tile * vtile, vb + j * 1024);
+                    else dma16(vrs, tile * kKV + vrow[i] < p.S ? vvo[i] : kOob, tile * vtile, vb + j * 1024);
+                }
             }
         }
     };
-    stage(0, 0);
+    auto stage = [&](int tile, int buf) { stage_part(tile, buf, 0); stage_part(tile, buf, 1); };
+    if constexpr (LOADER) {
+        if (wave >= WAVES) {
+            // a loader wave (with two of them, each takes every other piece): tile t+1 goes out right behind the barrier that proves every computing wave has left the buffer
+            // it overwrites (they arrive there after tile t-1); tile t is complete - `vmcnt(0)` - before the barrier publishes it
+            stage(0, 0);
+            for (int t = 0; t < ntiles; ++t) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+            }
+            return;
+        }
+    } else {
+        stage(0, 0);
+    }
 
     // ---- constant LDS region of the row-sum trick: rows of VP halves, [row][0] = 1, [row][1..15] = 0 (the rest is never read)
     if (ONES) {
-        for (int idx = threadIdx.x; idx < kKV * 2; idx += 64 * WAVES) {
+        for (int idx = threadIdx.x; idx < kKV * 2; idx += 64 * WAVES) {           // (a loader wave has left by now)
             const h8_t one = {(half_t)1, 0, 0, 0, 0, 0, 0, 0}, zero = {0, 0, 0, 0, 0, 0, 0, 0};
             *reinterpret_cast<__attribute__((address_space(3))) h8_t*>((uintptr_t)(ones0 + (idx >> 1) * VP * 2 + (idx & 1) * 16)) =
                 (idx & 1) ? zero : one;
@@ -222,14 +257,15 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
         const int buf = t & 1;
         // tile t: this wave's pieces have landed (the only DMAs outstanding), then everyone's - and every wave is done
         // reading buffer buf ^ 1 (tile t-1), so tile t+1 may go there
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (LOADER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the ones region's stores, first tile)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // The compiler puts an `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows an LDS-DMA it has
         // seen (it cannot tell the transposed read from the DMA's destination).  HOIST kernels therefore issue ALL LDS reads
         // of tile t first and the DMA of tile t+1 behind them; the others issue the DMA here and pay part of its latency
         // at their first transposed read.
-        if (!HOIST && t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        if (!LOADER && !HOIST && t + 1 < ntiles) stage(t + 1, buf ^ 1);
         SA_STAMP(0)
         const unsigned kb = lds0 + buf * C::TILE_BYTES + k_lane;
         const unsigned vb = lds0 + buf * C::TILE_BYTES + C::K_BYTES + v_lane;
@@ -249,12 +285,12 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int ks = 0; ks < NK; ++ks) kf[m][ks] = k_frag(m, ks);
+            if constexpr (!V_LATE) {
 #pragma unroll
-            for (int dm = 0; dm < DM; ++dm)
+                for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < ntiles) stage(t + 1, buf ^ 1);       // in flight during this tile's MFMAs and softmax
+                    for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -268,17 +304,26 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
                 s[m] = mfma_32x32x16(kfr, qf[ks], ks == 0 ? negm : s[m]);
             }
         }
+        if constexpr (V_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (dbg) asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
         SA_STAMP(1)
 
         // ---- softmax, base 2.  Element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this lane's query row.
         const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
         if (kv_left < kKV) {                                 // wave-uniform: only the ragged last tile masks
+            const int lim = kv_left - 4 * hh;                // (compared with constants: nothing loop-invariant to keep live)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    if (32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh >= kv_left) s[m][i] = -INFINITY;
+                    if (32 * m + (i & 3) + 8 * (i >> 2) >= lim) s[m][i] = -INFINITY;
         }
         float mxa = max3(s[0][0], s[0][1], s[0][2]), mxb = max3(s[1][0], s[1][1], s[1][2]);
 #pragma unroll
@@ -305,7 +350,15 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
         h8_t pf[4];
         float psum = 0.f;
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m) {
+            // HOIST kernels: the DMA of tile t+1 is issued HERE, behind every LDS read of tile t (see above) and in the
+            // VALU-only stretch of the tile (an LDS-DMA instruction issued among LDS reads costs 2-3x as much issue time):
+            // the K image before the first half of the exponentials, the V image before the second
+            if (!LOADER && HOIST && t + 1 < ntiles) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_part(t + 1, buf ^ 1, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 const float e0 = __builtin_amdgcn_exp2f(s[m][i]), e1 = __builtin_amdgcn_exp2f(s[m][i + 1]);
@@ -314,6 +367,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
                 pf[2 * m + (i >> 3)][i & 7] = pk[0];
                 pf[2 * m + (i >> 3)][(i & 7) + 1] = pk[1];
             }
+        }
         if (!ONES) l_run += psum;
         SA_STAMP(2)
 
@@ -358,40 +412,57 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void self_attn_fwd(SaParams p) {
     }
 }
 
-template <int NK, int WAVES, int MINW>
+template <int NK, int WAVES, int MINW, int D8 = 0, int NLOAD = 0>
 int launch(const SaParams& p0, hipStream_t st) {
     SaParams p = p0;
     p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
     p.xcd_map = ((p.Bc * p.H) % 8 == 0) ? 1 : 0;
-    const size_t lds = (size_t)SaCfg<NK>::LDS_BYTES;
+    const size_t lds = (size_t)SaCfg<NK, D8>::LDS_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, MINW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, MINW, D8, NLOAD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    DSC_LAUNCH((self_attn_fwd<NK, WAVES, MINW>), dim3(p.Bc * p.H * p.nqb), dim3(64 * WAVES), lds, st, p);
+    DSC_LAUNCH((self_attn_fwd<NK, WAVES, MINW, D8, NLOAD>), dim3(p.Bc * p.H * p.nqb), dim3(64 * (WAVES + NLOAD)), lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
 int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant): 0 = auto
 
+// Tilings (dsc_debug_set_self_attn_variant forces one; 0 = choose from the shape):
+//   1  4 waves of 32 query rows, every wave issues its share of the DMA
+//   2  8 waves (256 query rows share each K / V tile), likewise
+//   3  4 waves under a three-waves-per-SIMD register budget (the configuration that faulted with register-staged tiles)
+//   4 / 5  4 / 8 computing waves + 1 loader wave        6 / 7  4 / 8 computing waves + 2 loader waves
+//   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13)
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
     constexpr int MW = NK <= 5 ? 2 : 1;                       // waves per SIMD the registers allow: 256 / 512 per wave
-    // variant 3: three waves per SIMD (168 registers) - the configuration that FAULTED with register-staged tiles; kept
-    // reachable so that the tests can run it on the LDS-DMA staging
-    if (g_sa_variant == 3 && NK <= 4) return launch<(NK <= 4 ? NK : 3), 4, 3>(p, st);
-    // 8 waves (256 query rows share each K/V tile: half the DMA pieces and L2->LDS bytes per MFMA) once that still leaves
-    // >= 2 workgroups per CU
+    constexpr int NL = NK <= 4 ? NK : 3;                      // (instantiation guards: the loader kernels exist for NK <= 4)
+    const int v = g_sa_variant;
     const long long wg8 = (long long)p.Bc * p.H * ((p.L + 255) / 256);
-    if (NK <= 5 && ((g_sa_variant == 0 && wg8 >= 512) || g_sa_variant == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
-    // 4 waves (128 query rows) per workgroup when that gives >= 256 of them
     const long long wg4 = (long long)p.Bc * p.H * ((p.L + 127) / 128);
-    if (wg4 >= 256 || g_sa_variant == 1) return launch<NK, 4, MW>(p, st);
+    if (NK <= 4) {
+        const bool compact = NK == 3 && p.d == 40;
+        // (NK = 4 does not fit 168 registers next to its own DMA plan: its three-waves-per-SIMD kernel is a loader one,
+        // and one loader wave alone cannot carry its 17 pieces per tile: NK = 4 always gets two)
+        constexpr int N3 = NK <= 3 ? NK : 3;
+        if (v == 3) return NK <= 3 ? launch<N3, 4, 3>(p, st) : launch<NL, 4, 3, 0, 2>(p, st);
+        if (v == 4) return NK <= 3 ? launch<N3, 4, 3, 0, 1>(p, st) : launch<NL, 4, 3, 0, 2>(p, st);
+        if (v == 5) return NK <= 3 ? launch<N3, 8, 2, 0, 1>(p, st) : launch<NL, 8, 2, 0, 2>(p, st);
+        if (v == 6) return launch<NL, 4, 3, 0, 2>(p, st);
+        if (v == 7) return launch<NL, 8, 2, 0, 2>(p, st);
+        if (v == 8 && compact) return launch<3, 4, 3, 5, 2>(p, st);
+        if (v == 9 && compact) return launch<3, 8, 2, 5, 2>(p, st);
+        if (v == 10 && compact) return launch<3, 8, 2, 5, 1>(p, st);
+        if (v == 0 && wg8 >= 256 && NK == 3) return launch<3, 8, 2, 0, 1>(p, st);      // provisional (tools/mb_sa.py)
+    }
+    if (NK <= 5 && ((v == 0 && wg8 >= 512) || v == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
+    if (wg4 >= 256 || v == 1) return launch<NK, 4, MW>(p, st);
     const long long wg2 = (long long)p.Bc * p.H * ((p.L + 63) / 64);
-    if (wg2 >= 128 || NK >= 6) return launch<NK, 2, MW>(p, st);
-    return launch<NK, 1, MW>(p, st);
+    if (wg2 >= 128 || NK >= 6) return launch<NK, 2, MW>(p, st);      // (NK >= 6: one wave alone would carry 40 DMA offsets)
+    return launch<(NK <= 5 ? NK : 3), 1, MW>(p, st);
 }
 
 bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }

@@ -155,7 +155,11 @@ _KERNEL_MAX_KEYS_PACKED = 384   # region_xattn_packed.hip kChunksMax x 96: long 
 
 def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None,
                       comp=None):
+    """comp: the caller's (ids, rows) of `w`, None = compress `w` here (cached per tensor version), False = `w` is a static
+    buffer whose CONTENTS change between replays of a captured step: read it densely, derive nothing from its values."""
     S = k.shape[2 if layout == "bhld" else 1]
+    if comp is False:
+        packed_kv, comp = None, None
     if S > _KERNEL_MAX_KEYS:
         # long prompts: the prepared-operand kernels walk the keys in chunks of 96 with an online softmax (fp32 scores, default
         # weight_func, compressible table); anything else runs the reference's op sequence as library kernels
@@ -288,7 +292,7 @@ class _RegionProcessor:
             w = region_prompt["region_state"][img_sequence_length]          # KeyError when L is not a level (:481)
             groups = region_prompt.get("n_std_groups", self.n_std_groups)
             pre = region_prompt.get("compressed")                           # the pipeline's static (ids, rows) buffers
-            comp = pre.get(img_sequence_length) if isinstance(pre, dict) else None
+            comp = pre.get(img_sequence_length) if isinstance(pre, dict) else (False if pre is False else None)
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
                                     groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp)
         elif not is_self:

@@ -1031,8 +1031,8 @@ class StableDiffusionPipeline:
         # kernels) reads the DENSE table - so the graph must be given a static device copy that each generation refreshes in
         # place, never the first generation's own tensors (a later generation with the same shapes would replay old masks).
         need_dense = isinstance(region_state, dict) and bool(region_state) and (
-            comp_cpu is None or self._weight_func_key(weight_func) != "default" or text.shape[1] > 96
-            or not self._all_cross_attention_packable())
+            comp_cpu is None or self._weight_func_key(weight_func) != "default" or text.shape[1] > 384
+            or not self._all_cross_attention_packable())         # (<= 384 text keys: the chunked prepared-operand kernels)
         if (st is not None and (st["compressed"] is None) == (comp_cpu is None)
                 and (st["dense"] is None) == (not need_dense)):
             done = st.get("done")
@@ -1065,7 +1065,10 @@ class StableDiffusionPipeline:
         self._refresh_text_kv(st["text"])
         kw = dict(cross_attention_kwargs)
         # without a dense copy the dict only supplies the level keys / shapes: no kernel of the captured step reads it
-        kw["region_prompt"] = {"region_state": st["dense"] if need_dense else region_state, "compressed": st["compressed"],
+        # "compressed": False = the tables are static buffers refreshed in place: the processors must read them densely and
+        # must not derive (and bake into the capture) a compressed form from the values they hold during the capture
+        kw["region_prompt"] = {"region_state": st["dense"] if need_dense else region_state,
+                               "compressed": st["compressed"] if st["compressed"] is not None else (False if need_dense else None),
                                "sigma": st["sigma"], "weight_func": weight_func,
                                "n_std_groups": n_img if n_std_groups is None else n_std_groups}
 
