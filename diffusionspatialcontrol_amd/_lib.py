@@ -78,6 +78,8 @@ _SIGNATURES = {
     "dsc_linear_rows_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 3 + [ctypes.c_int64] * 2 + [ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_linear_ln_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                           [ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_float, _vp, ctypes.c_int, _vp]),
+    "dsc_linear_qkv_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_add_layernorm": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_geglu": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
 }

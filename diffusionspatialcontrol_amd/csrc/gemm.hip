@@ -44,6 +44,10 @@ struct GemmParams {
     const float* ln_c;           // [N] cvec[n] = sum_k w[n, k]
     float* ln_out;               // [M][N/64][2] partials of THIS GEMM's fp16 output rows (for the next folded LayerNorm)
     int ln_nb; float ln_inv_c, ln_eps;
+    // fused QKV projection with head-major K / V (dsc_linear_qkv_f16): output columns [0, C) go to `out` (the queries, row
+    // stride ldo), columns [C, 3C) to kv[which][b][h][l][dd] - each head's keys / values contiguous, so that the flash
+    // kernel's 64-key tiles are plain contiguous 1-KiB DMA pieces instead of 80-byte row segments 1920 bytes apart
+    half_t* kv; int kv_C, kv_H, kv_d, kv_L, kv_B;
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -220,6 +224,18 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
         }
     } else {
         // output tile 128 x 64: 8 chunks per row -> 1024 chunks, 4 per thread; a row's 8 chunks = one 128-B segment
+        const bool scat = p.kv != nullptr && n0 >= p.kv_C;       // workgroup-uniform (C is a multiple of the 64-column block)
+        long long kv_col = 0;
+        int kv_b0 = 0, kv_l0 = 0;
+        if (scat) {                                               // this thread's chunk column -> (k | v, head, channel)
+            int cc = n0 - p.kv_C + ech * 8;
+            const int which = cc >= p.kv_C ? 1 : 0;
+            cc -= which * p.kv_C;
+            const int hd = cc / p.kv_d;
+            kv_col = ((long long)(which * p.kv_B) * p.kv_H + hd) * p.kv_L * p.kv_d + (cc - hd * p.kv_d);
+            kv_b0 = m0 / p.kv_L;                                  // scalar: the block's first token row
+            kv_l0 = m0 - kv_b0 * p.kv_L;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
@@ -241,7 +257,13 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
                     const float f = (float)o[j];                 // statistics of the fp16 row, as the LayerNorm kernel takes them
                     s1 += f; s2 += f * f;
                 }
-                *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
+                if (scat) {
+                    int bb = kv_b0, ll = kv_l0 + row;
+                    while (ll >= p.kv_L) { ll -= p.kv_L; ++bb; }
+                    *reinterpret_cast<h8_t*>(p.kv + kv_col + ((long long)bb * p.kv_H * p.kv_L + ll) * p.kv_d) = o;
+                } else {
+                    *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
+                }
             }
             if (p.ln_out) {                                       // wave-uniform
 #pragma unroll
@@ -271,10 +293,36 @@ extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, co
                              dtype, stream);
 }
 
+namespace {
+int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
+                const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
+                int dtype, void* stream, void* kv_out, int heads, int seq_len);
+}
+
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                  int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                                  const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
                                  int dtype, void* stream) {
+    return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldr, ldo, geglu, ln_in, ln_nb, ln_cvec, ln_eps, ln_out, dtype,
+                       stream, nullptr, 0, 0);
+}
+
+extern "C" int dsc_linear_qkv_f16(const void* x, const void* w, const void* bias, void* q_out, void* kv_out,
+                                  int64_t M, int C, int K, int64_t ldx, int64_t ldq, int heads, int seq_len,
+                                  const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, int dtype, void* stream) {
+    if (!kv_out || heads <= 0 || seq_len <= 0 || C <= 0) return DSC_ERR_BAD_ARG;
+    if (C % 64 != 0 || C % heads != 0 || (C / heads) % 8 != 0 || M % seq_len != 0) return DSC_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(kv_out) & 15) return DSC_ERR_UNSUPPORTED;
+    return linear_impl(x, w, bias, nullptr, q_out, M, 3 * C, K, ldx, 0, ldq, 0, ln_in, ln_nb, ln_cvec, ln_eps, nullptr, dtype,
+                       stream, kv_out, heads, seq_len);
+}
+
+namespace {
+int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
+                const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
+                int dtype, void* stream, void* kv_out, int heads, int seq_len) {
     if ((ln_in && (!ln_cvec || ln_nb <= 0)) || (ln_out && geglu)) return DSC_ERR_BAD_ARG;
     if (ln_in && !al16(ln_cvec)) return DSC_ERR_UNSUPPORTED;       // read as float4 pairs
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
@@ -289,6 +337,10 @@ extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias,
     p.out = static_cast<half_t*>(out);
     p.M = (int)M; p.N = N; p.K = K; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.ln_in = ln_in; p.ln_c = ln_cvec; p.ln_out = ln_out; p.ln_nb = ln_nb; p.ln_inv_c = 1.f / (float)K; p.ln_eps = ln_eps;
+    if (kv_out) {
+        p.kv = static_cast<half_t*>(kv_out);
+        p.kv_C = N / 3; p.kv_H = heads; p.kv_d = N / 3 / heads; p.kv_L = seq_len; p.kv_B = (int)(M / seq_len);
+    }
     const int mb = (int)((M + BM - 1) / BM);
     const int nb = geglu ? N / 64 : N / BN;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -308,3 +360,5 @@ extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias,
     else DSC_LAUNCH((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
+}  // namespace
+

@@ -67,7 +67,7 @@ struct SaCfg {
     static constexpr int K_BYTES = kKV * KP * 2, V_BYTES = kKV * VP * 2;
     static constexpr int TILE_BYTES = K_BYTES + V_BYTES;    // one (K, V) buffer
     static constexpr int ONES_BYTES = ONES ? kKV * VP * 2 + 64 : 0;
-    static constexpr int LDS_BYTES = 2 * TILE_BYTES + ONES_BYTES + 64;       // + slack for the compact image's over-reads
+    static constexpr int lds_bytes(int nbuf) { return nbuf * TILE_BYTES + ONES_BYTES + 64; }   // + slack: the compact image's over-reads
     static_assert(D8 == 0 || ((D8 & 1) && D8 > 2 * NK - 2 && D8 <= 2 * NK), "compact rows: odd d/8 that needs exactly NK k-steps");
 };
 
@@ -123,7 +123,11 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     constexpr bool V_LATE = HOIST && LOADER && (MINW >= 3 || WAVES + NLOAD > 8);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_char_t*)smem;
-    const unsigned ones0 = lds0 + 2 * C::TILE_BYTES;
+    // loader kernels keep a ring of THREE tile buffers: tile t+2 is issued behind the barrier of tile t, so a tile has two
+    // tile times to arrive (with two buffers the computing waves waited ~590 of ~1900 cycles per tile at that barrier for the
+    // loader's issue + L2 latency chain); the others double-buffer
+    constexpr int NBUF = LOADER ? 3 : 2;
+    const unsigned ones0 = lds0 + NBUF * C::TILE_BYTES;
 
     int bh, qb;
     {
@@ -195,10 +199,16 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
             // a loader wave (with two of them, each takes every other piece): tile t+1 goes out right behind the barrier that proves every computing wave has left the buffer
             // it overwrites (they arrive there after tile t-1); tile t is complete - `vmcnt(0)` - before the barrier publishes it
             stage(0, 0);
+            if (ntiles > 1) stage(1, 1);
+            // pieces this wave issues per tile, at least: what may stay outstanding while the OLDER tile is known to be complete
+            constexpr int kKeep = KC / NISSUE + VC / NISSUE;
             for (int t = 0; t < ntiles; ++t) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+                // tile t has landed once only (a part of) tile t+1's pieces are outstanding: vmcnt retires in issue order
+                if (t + 1 < ntiles) __builtin_amdgcn_s_waitcnt((kKeep & 15) | (7 << 4) | (15 << 8) | ((kKeep >> 4) << 14));
+                else __builtin_amdgcn_s_waitcnt((0 & 15) | (7 << 4) | (15 << 8));
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();          // publishes tile t; every computing wave has left tile t-1's buffer
+                if (t + 2 < ntiles) stage(t + 2, (t + 2) % 3);
             }
             return;
         }
@@ -253,8 +263,10 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
+    int buf = NBUF - 1;
     for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+        buf = buf + 1 == NBUF ? 0 : buf + 1;                 // t % NBUF
+        const int nbuf1 = buf + 1 == NBUF ? 0 : buf + 1;     // (t + 1) % NBUF: where a non-loader kernel stages the next tile
         // tile t: this wave's pieces have landed (the only DMAs outstanding), then everyone's - and every wave is done
         // reading buffer buf ^ 1 (tile t-1), so tile t+1 may go there
         if (LOADER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the ones region's stores, first tile)
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
         // seen (it cannot tell the transposed read from the DMA's destination).  HOIST kernels therefore issue ALL LDS reads
         // of tile t first and the DMA of tile t+1 behind them; the others issue the DMA here and pay part of its latency
         // at their first transposed read.
-        if (!LOADER && !HOIST && t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        if (!LOADER && !HOIST && t + 1 < ntiles) stage(t + 1, nbuf1);
         SA_STAMP(0)
         const unsigned kb = lds0 + buf * C::TILE_BYTES + k_lane;
         const unsigned vb = lds0 + buf * C::TILE_BYTES + C::K_BYTES + v_lane;
@@ -356,7 +368,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
             // the K image before the first half of the exponentials, the V image before the second
             if (!LOADER && HOIST && t + 1 < ntiles) {
                 __builtin_amdgcn_sched_barrier(0);
-                stage_part(t + 1, buf ^ 1, m);
+                stage_part(t + 1, nbuf1, m);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -417,7 +429,7 @@ int launch(const SaParams& p0, hipStream_t st) {
     SaParams p = p0;
     p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
     p.xcd_map = ((p.Bc * p.H) % 8 == 0) ? 1 : 0;
-    const size_t lds = (size_t)SaCfg<NK, D8>::LDS_BYTES;
+    const size_t lds = (size_t)SaCfg<NK, D8>::lds_bytes(NLOAD > 0 ? 3 : 2);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, MINW, D8, NLOAD>),
@@ -435,7 +447,7 @@ int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant
 //   2  8 waves (256 query rows share each K / V tile), likewise
 //   3  4 waves under a three-waves-per-SIMD register budget (the configuration that faulted with register-staged tiles)
 //   4 / 5  4 / 8 computing waves + 1 loader wave        6 / 7  4 / 8 computing waves + 2 loader waves
-//   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13)
+//   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13); 11 / 12  as 1 / 2 with it
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
     constexpr int MW = NK <= 5 ? 2 : 1;                       // waves per SIMD the registers allow: 256 / 512 per wave
@@ -456,9 +468,16 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         if (v == 8 && compact) return launch<3, 4, 3, 5, 2>(p, st);
         if (v == 9 && compact) return launch<3, 8, 2, 5, 2>(p, st);
         if (v == 10 && compact) return launch<3, 8, 2, 5, 1>(p, st);
-        if (v == 0 && wg8 >= 256 && NK == 3) return launch<3, 8, 2, 0, 1>(p, st);      // provisional (tools/mb_sa.py)
+        if (v == 11 && compact) return launch<3, 4, 2, 5, 0>(p, st);
+        if (v == 12 && compact) return launch<3, 8, 2, 5, 0>(p, st);
+        // measured (tools/mb_sa.py, head-major K / V): at batch 1 (+CFG) the SD1.5 64x64 level offers 256 workgroups of 256
+        // query rows - one per CU, 8 computing waves + a loader wave: 64 us against 70 for two 4-wave workgroups per CU
+        // that issue their own DMA; at 8 images the 4-wave workgroups win (480 vs 505 us)
+        if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return compact ? launch<3, 8, 2, 5, 1>(p, st) : launch<3, 8, 2, 0, 1>(p, st);
+        if (v == 0 && compact && wg4 >= 256) return launch<3, 4, 2, 5, 0>(p, st);
     }
-    if (NK <= 5 && ((v == 0 && wg8 >= 512) || v == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
+    if (NK == 5 && ((v == 0 && wg8 >= 512) || v == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
+    if (NK <= 4 && v == 2) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
     if (wg4 >= 256 || v == 1) return launch<NK, 4, MW>(p, st);
     const long long wg2 = (long long)p.Bc * p.H * ((p.L + 63) / 64);
     if (wg2 >= 128 || NK >= 6) return launch<NK, 2, MW>(p, st);      // (NK >= 6: one wave alone would carry 40 DMA offsets)

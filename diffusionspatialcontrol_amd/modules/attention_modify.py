@@ -254,15 +254,26 @@ class _RegionProcessor:
         if is_self and fused_qkv is not None and attn.to_q.bias is None:
             # self-attention: q, k, v from ONE [3C, C] GEMM; the three [B, L, H, d] operands are strided views of it
             B, L, _ = hidden_states.shape
-            if _ln_fold is not None:
-                w2, b2, cvec = _ln_fold.folded(attn, "qkv", fused_qkv())
-                qkv = ops.linear_ln(hidden_states, w2, b2, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
+            wq = fused_qkv()
+            if ops.linear_qkv_covers(hidden_states, wq, H):
+                # the GEMM's epilogue writes K / V head-major: the flash kernel's key tiles are then contiguous DMA pieces
+                if _ln_fold is not None:
+                    w2, b2, cvec = _ln_fold.folded(attn, "qkv", wq)
+                    q4, k4, v4 = ops.linear_qkv(hidden_states, w2, b2, H, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
+                else:
+                    q4, k4, v4 = ops.linear_qkv(hidden_states, wq, None, H)
+                C = wq.shape[0] // 3
+                d = C // H
             else:
-                qkv = ops.linear(hidden_states, fused_qkv())
-            C = qkv.shape[-1] // 3
-            d = C // H
+                if _ln_fold is not None:
+                    w2, b2, cvec = _ln_fold.folded(attn, "qkv", wq)
+                    qkv = ops.linear_ln(hidden_states, w2, b2, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
+                else:
+                    qkv = ops.linear(hidden_states, wq)
+                C = qkv.shape[-1] // 3
+                d = C // H
+                q4, k4, v4 = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
             S = L
-            q4, k4, v4 = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
         else:
             if _ln_fold is not None:
                 w2, b2, cvec = _ln_fold.folded(attn, "q", attn.to_q.weight, attn.to_q.bias)

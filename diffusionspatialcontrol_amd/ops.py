@@ -367,6 +367,45 @@ def linear_ln(x, weight, bias, *, residual=None, geglu=False, ln=None, ln_stats=
     return (out, stats) if ln_stats else out
 
 
+USE_QKV_HEAD_MAJOR = os.environ.get("DSC_QKV_HEAD_MAJOR", "1") != "0"
+
+
+def linear_qkv_covers(x, weight, heads):
+    """True when dsc_linear_qkv_f16 takes the fused self-attention projection of x [B, L, K] by weight [3C, K]"""
+    if not (USE_QKV_HEAD_MAJOR and x.dim() == 3 and x.dtype == torch.float16 and weight.dtype == torch.float16):
+        return False
+    B, L, K = x.shape
+    C = weight.shape[0] // 3
+    return (weight.shape[0] == 3 * C and C % 64 == 0 and C % heads == 0 and (C // heads) % 8 == 0
+            and linear_kernel_covers(B * L, 3 * C, K, x.dtype) and x.stride(-1) == 1 and weight.is_contiguous())
+
+
+def linear_qkv(x, weight, bias, heads, ln=None):
+    """The self-attention q / k / v projection as one GEMM with the head split of K and V done by its epilogue
+    (dsc_linear_qkv_f16): x [B, L, K], weight [3C, K] -> (q4, k4, v4), each a [B, L, heads, d] VIEW: q4 of a [B, L, C]
+    tensor, k4 / v4 of a head-major [2, B, heads, L, d] one (a head's keys / values contiguous).  ln as in linear_ln."""
+    _require_gpu(x, weight)
+    B, L, K = x.shape
+    C = weight.shape[0] // 3
+    d = C // heads
+    M = B * L
+    x2 = x.reshape(M, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
+        raise ValueError("linear_qkv: unit inner stride and 16-byte aligned rows are required")
+    q = torch.empty((B, L, C), dtype=x.dtype, device=x.device)
+    kv = torch.empty((2, B, heads, L, d), dtype=x.dtype, device=x.device)
+    part, cvec, eps, nb = None, None, 0.0, 0
+    if ln is not None:
+        part, cvec, eps = ln
+        nb = part.shape[1]
+        if part.shape[0] != M or part.dtype != torch.float32 or not part.is_contiguous() or cvec.numel() != 3 * C:
+            raise ValueError("linear_qkv: statistics / cvec do not match the operands")
+    rc = _lib.load_library().dsc_linear_qkv_f16(_p(x2), _p(weight), _p(bias), _p(q), _p(kv), M, C, K, x2.stride(0), C, heads, L,
+                                                _p(part), nb, _p(cvec), float(eps), 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_linear_qkv_f16")
+    return q.view(B, L, heads, d), kv[0].permute(0, 2, 1, 3), kv[1].permute(0, 2, 1, 3)
+
+
 def linear(x, weight, bias=None, residual=None, geglu=False):
     """x @ weight.T (+ bias) (+ residual), or the fused GEGLU of [x @ weight.T + bias]; x [..., K], weight [N, K].
 

@@ -276,6 +276,18 @@ int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void
                       int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                       const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
                       int dtype, void* stream);
+/*
+ * The self-attention branch's fused q / k / v projection (reference attention_modify.py:458-474: `attn.to_q / to_k / to_v` on
+ * the same hidden states, then `.view(batch, -1, heads, head_dim).transpose(1, 2)`) as ONE GEMM over w = [Wq; Wk; Wv]
+ * ([3C, K]) whose epilogue already performs the head split for K and V: columns [0, C) -> q_out [M, C] (row stride ldq),
+ * columns [C, 3C) -> kv_out [2][M / seq_len][heads][seq_len][C / heads] (fp16, 16-byte aligned) - each head's keys / values
+ * contiguous, the layout dsc_self_attn_fwd's 64-key LDS-DMA tiles want (contiguous 1-KiB pieces instead of C/heads-element
+ * row segments 3C elements apart).  Same LayerNorm-folding arguments as dsc_linear_ln_f16 (ln_in NULL = plain GEMM).
+ * Needs C % 64 == 0, (C / heads) % 8 == 0, K % 64 == 0, M % seq_len == 0.
+ */
+int dsc_linear_qkv_f16(const void* x, const void* w, const void* bias, void* q_out, void* kv_out,
+                       int64_t M, int C, int K, int64_t ldx, int64_t ldq, int heads, int seq_len,
+                       const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, int dtype, void* stream);
 
 /*
  * 3x3 / pad 1 convolution with few input channels (<= 16) - the UNet's `conv_in` (4 -> 320; reference

@@ -134,7 +134,7 @@ def test_self_attention(ops, B, H, L, d):
         assert (out2.float().cpu() - ref2).abs().max().item() < 3e-3
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("B,H,L,d", [(2, 8, 4096, 40), (2, 10, 1000, 64), (1, 8, 520, 80), (2, 4, 300, 32), (3, 8, 77, 40)])
 def test_self_attention_tiling_variants(ops, variant, B, H, L, d):
     """every tiling of the flash kernel, forced through dsc_debug_set_self_attn_variant: 1 = 4 waves per workgroup, 2 = 8 waves
@@ -157,7 +157,8 @@ def test_self_attention_tiling_variants(ops, variant, B, H, L, d):
     finally:
         lib.dsc_debug_set_self_attn_variant(0)
     err = (out.float().cpu() - ref).abs()
-    assert err.max().item() < 3e-3 and err.mean().item() < 2e-4, (err.max().item(), err.mean().item())
+    # the spiked rows' outputs are single value rows of magnitude up to ~4.5, where one fp16 ulp is 3.9e-3: 4e-3 absolute
+    assert err.max().item() < 4e-3 and err.mean().item() < 2e-4, (err.max().item(), err.mean().item())
     assert torch.equal(out, again)
 
 
@@ -419,6 +420,37 @@ def test_linear_layernorm_folding(ops, M, C, N, geglu):
     y0 = ops.linear(hk, w, b, geglu=geglu)
     assert (y.float() - y0.float()).abs().mean().item() < 2e-3
     assert torch.equal(y, ops.linear_ln(s, w2, b2, geglu=geglu, ln=(st, cvec, 1e-5)))
+
+
+@pytest.mark.parametrize("B,L,C,H,fold", [(2, 4096, 320, 8, True), (2, 1024, 640, 8, False), (3, 576, 320, 8, True), (16, 64, 320, 5, False),
+                                         (1, 9216, 320, 8, False)])
+def test_linear_qkv_head_major(ops, B, L, C, H, fold):
+    """dsc_linear_qkv_f16: the fused q / k / v projection whose epilogue writes K and V head-major ([2, B, H, L, d]) equals
+    the plain fused projection bit for bit (same GEMM, another store address), with and without a folded LayerNorm; token
+    blocks that straddle two batch rows (L = 576, 64) included."""
+    g = torch.Generator().manual_seed(B * L + C)
+    x = (torch.randn(B, L, C, generator=g) * 1.3 + 0.2).half().cuda()
+    w = (torch.randn(3 * C, C, generator=g) / C ** 0.5).half().cuda()
+    assert ops.linear_qkv_covers(x, w, H)
+    d = C // H
+    if fold:
+        gamma, beta = (torch.randn(C, generator=g) * 0.3 + 1).half().cuda(), (torch.randn(C, generator=g) * 0.2).half().cuda()
+        w2, b2, cvec = ops.fold_layernorm(w, None, gamma, beta)
+        # row partials as the producing GEMM's epilogue would leave them: per 64-column block (sum, sum of squares)
+        xb = x.float().reshape(B * L, C // 64, 64)
+        part = torch.stack([xb.sum(-1), (xb * xb).sum(-1)], dim=-1).contiguous()
+        ln = (part, cvec, 1e-5)
+        ref = ops.linear_ln(x, w2, b2, ln=ln)
+        q4, k4, v4 = ops.linear_qkv(x, w2, b2, H, ln=ln)
+    else:
+        ref = ops.linear_ln(x, w, None)
+        q4, k4, v4 = ops.linear_qkv(x, w, None, H)
+    rq, rk, rv = (ref[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+    assert q4.shape == k4.shape == v4.shape == (B, L, H, d)
+    assert k4.stride() == (H * L * d, d, L * d, 1)                     # a head's keys are contiguous
+    assert torch.equal(q4, rq) and torch.equal(k4, rk) and torch.equal(v4, rv)
+    # and the flash kernel on the head-major views equals the flash kernel on the token-major ones
+    assert torch.equal(ops.self_attention(q4, k4, v4), ops.self_attention(rq, rk, rv))
 
 
 @pytest.mark.parametrize("M,C", [(8192, 320), (2048, 640), (512, 1280), (300, 64)])
