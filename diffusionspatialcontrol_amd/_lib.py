@@ -42,6 +42,8 @@ _SIGNATURES = {
                              [ctypes.c_float, _vp, ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, ctypes.c_size_t, _vp]),
     "dsc_region_xattn_std": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_i64p] * 2 +
                              [ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, _vp, ctypes.c_size_t, _vp]),
+    "dsc_region_xattn_std_masked": (ctypes.c_int, [_vp, _vp] + [ctypes.c_int] * 6 + [_i64p] * 2 +
+                                    [ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp, _i64p, _vp, _vp, ctypes.c_size_t, _vp]),
     "dsc_xattn_kv_pack_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "dsc_xattn_kv_pack": (ctypes.c_int, [_vp] * 3 + [ctypes.c_int] * 4 + [_i64p] * 2 + [ctypes.c_int, _vp]),
     "dsc_region_xattn_fwd_packed": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 8 + [_i64p] * 2 +

@@ -84,12 +84,18 @@ __global__ __launch_bounds__(kThreads, 2) void xattn_stats(XattnParams p) {   //
         if (t > 0) load_q_frags<NK>(p, qf, b, h, row, hh);
         f16x_t acc[3];
         scores<NK, REF16>(p, Ks, qf, acc, r, hh, p.scale);
+        const float* mrow = p.mask ? p.mask + (long long)(b * p.H + h) * p.msbh + (long long)row * p.msl : nullptr;   // wave-uniform test
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int s = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const float a = (row_ok && s < p.S) ? acc[m][i] : 0.f;
+                float a = acc[m][i];
+                if (mrow) {                                   // attn_weight += attn_bias (:91): an fp16 tensor in the fp16 pipeline
+                    a += mrow[min(s, p.S - 1)];
+                    if (REF16) a = round_f16(a);
+                }
+                a = (row_ok && s < p.S) ? a : 0.f;
                 s1 += a;
                 s2 += a * a;
             }
@@ -381,9 +387,18 @@ extern "C" int dsc_region_xattn_std(const void* q, const void* k, int Bc, int H,
                                     const int64_t q_strides[3], const int64_t k_strides[3], float scale, int dtype,
                                     unsigned flags, float* std_out, void* workspace, size_t workspace_bytes,
                                     void* stream) {
+    return dsc_region_xattn_std_masked(q, k, Bc, H, L, S, d, n_std_groups, q_strides, k_strides, scale, dtype, flags, nullptr,
+                                       nullptr, std_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dsc_region_xattn_std_masked(const void* q, const void* k, int Bc, int H, int L, int S, int d, int n_std_groups,
+                                           const int64_t q_strides[3], const int64_t k_strides[3], float scale, int dtype,
+                                           unsigned flags, const float* mask, const int64_t mask_strides[2], float* std_out,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_common(q, k, Bc, H, L, S, d, n_std_groups, q_strides, k_strides, dtype);
     if (rc != DSC_OK) return rc;
-    if (!std_out) return DSC_ERR_BAD_ARG;
+    if (!std_out || (mask && !mask_strides)) return DSC_ERR_BAD_ARG;
+    if (mask && ((reinterpret_cast<uintptr_t>(mask) & 3) || mask_strides[0] < 0 || mask_strides[1] < 0)) return DSC_ERR_UNSUPPORTED;
     XattnParams p{};
     p.q = static_cast<const half_t*>(q); p.k = static_cast<const half_t*>(k);
     p.scale = scale > 0.f ? scale : 1.0f / sqrtf((float)d);
@@ -391,6 +406,7 @@ extern "C" int dsc_region_xattn_std(const void* q, const void* k, int Bc, int H,
     p.qsb = q_strides[0]; p.qsl = q_strides[1]; p.qsh = q_strides[2];
     p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
     p.flags = flags; p.std_out = std_out;
+    if (mask) { p.mask = mask; p.msbh = mask_strides[0]; p.msl = mask_strides[1]; }
     plan(p);
     const size_t need = (size_t)n_std_groups * p.npart * 2 * sizeof(double);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;

@@ -153,11 +153,44 @@ def _region_attention_long(q, k, v, w, sigma, weight_func, layout, n_std_groups,
 _KERNEL_MAX_KEYS_PACKED = 384   # region_xattn_packed.hip kChunksMax x 96: long prompts (77 n tokens) on the chunked kernels
 
 
+def _region_attention_masked(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale, ref16, mask):
+    """The region path with an additive attention mask (reference :85-97 / :144-170): the mask enters the scores BEFORE the
+    statistics, so the std comes from dsc_region_xattn_std_masked; mask + w * sigma * std is then the final bias of the
+    forward kernel (one dense fp32 [Bc*H, L, S] tensor - this is the rarely-taken path, app.py never passes a mask)."""
+    qh = q if layout == "bhld" else q.transpose(1, 2)
+    Bc, H, L, d = qh.shape
+    S = k.shape[2 if layout == "bhld" else 1]
+    if S > _KERNEL_MAX_KEYS:
+        raise NotImplementedError("attention masks with more than 96 text keys")
+    m3 = mask.float()
+    while m3.dim() < 3:
+        m3 = m3.unsqueeze(0)
+    w_dev = resident_table(w, q.device)
+    rep = (Bc * H) // w_dev.shape[0]
+    if weight_func is None or weight_func_is_default(weight_func):
+        std = ops.region_xattn_std(q, k, layout=layout, n_std_groups=n_std_groups, scale=scale, ref_fp16_rounding=ref16, mask=m3)
+        sig = sigma.float() if (torch.is_tensor(sigma) and sigma.is_cuda) else float(sigma)
+        if ref16:                                                                   # 0-dim fp16 tensors in the fp16 pipeline
+            std = std.half().float()
+            sig = torch.as_tensor(sig).half().float() if not torch.is_tensor(sig) else sig.half().float()
+        grp = (torch.arange(Bc * H, device=q.device) // H) % n_std_groups           # row bh = b * H + h belongs to group b % n
+        region = torch.repeat_interleave(w_dev, rep, dim=0) * sig * std[grp].reshape(-1, 1, 1)
+    else:
+        kh = k if layout == "bhld" else k.transpose(1, 2)
+        sf = scale if scale else 1.0 / math.sqrt(d)
+        scores = ((qh @ kh.transpose(-2, -1)) * sf).reshape(-1, L, S) + m3.to(qh.dtype)
+        region = torch.repeat_interleave(torch.broadcast_to(weight_func(w_dev, sigma, scores), w_dev.shape).float(), rep, dim=0)
+    bias = (region + m3).contiguous()
+    return ops.region_xattn(q, k, v, bias, 1.0, layout=layout, scale=scale, bias_is_final=True, ref_fp16_rounding=ref16)
+
+
 def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None,
-                      comp=None):
+                      comp=None, mask=None):
     """comp: the caller's (ids, rows) of `w`, None = compress `w` here (cached per tensor version), False = `w` is a static
     buffer whose CONTENTS change between replays of a captured step: read it densely, derive nothing from its values."""
     S = k.shape[2 if layout == "bhld" else 1]
+    if mask is not None:
+        return _region_attention_masked(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale, ref16, mask)
     if comp is False:
         packed_kv, comp = None, None
     if S > _KERNEL_MAX_KEYS:
@@ -195,19 +228,39 @@ def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scal
 def scaled_dot_product_attention_regionstate(query, key, value, attn_mask=None, dropout_p=0.0, is_causal=False,
                                              scale=None, weight_func=None, region_state=None, sigma=None,
                                              n_std_groups=1) -> torch.Tensor:
-    """Same signature and result as attention_modify.py:74-103; query [Bc,H,L,d], key/value [Bc,H,S,d]."""
-    if attn_mask is not None or is_causal or dropout_p != 0.0:
-        raise NotImplementedError("attn_mask / is_causal / dropout are not on the hot path (never used by app.py)")
+    """Same signature and result as attention_modify.py:74-103; query [Bc,H,L,d], key/value [Bc,H,S,d].
+
+    attn_mask as the reference treats it (:85-91): a FLOAT mask is added in place into an [L, S] bias (`attn_bias +=
+    attn_mask`), so it must broadcast INTO [L, S] - a [B, H, ., S] mask raises the same RuntimeError torch raises there -
+    and the std is taken over the masked scores; a BOOL mask only rewrites itself (`attn_mask.masked_fill_(~attn_mask,
+    -inf)` on a bool tensor turns every element True) and never reaches the scores - reproduced, not fixed."""
+    if is_causal or dropout_p != 0.0:
+        raise NotImplementedError("is_causal / dropout are not on the hot path (never used by app.py)")
+    mask = None
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            attn_mask.masked_fill_(attn_mask.logical_not(), float("-inf"))          # :86-87, all True afterwards
+        else:
+            L, S = query.size(-2), key.size(-2)
+            mask = torch.zeros(L, S, dtype=query.dtype, device=query.device)
+            mask += attn_mask                                                        # :89 (raises unless it broadcasts into [L, S])
     return _region_attention(query, key, value, region_state, sigma, weight_func, "bhld", n_std_groups, scale,
-                             ref16=query.dtype == torch.float16)
+                             ref16=query.dtype == torch.float16, mask=mask)
 
 
 def get_attention_scores(attn, query, key, attention_mask=None):
-    """attention_modify.py:39-70 (used by the generic weight_func path of callers that want raw scores)."""
-    if attention_mask is not None:
-        raise NotImplementedError("attention masks are not on the hot path")
-    return torch.baddbmm(torch.empty(query.shape[0], query.shape[1], key.shape[1], dtype=query.dtype, device=query.device),
-                         query, key.transpose(-1, -2), beta=0, alpha=attn.scale)
+    """attention_modify.py:39-70 (used by the generic weight_func path of callers that want raw scores): library baddbmm,
+    the mask as its additive input (beta = 1)."""
+    if attn.upcast_attention:
+        query, key = query.float(), key.float()
+    if attention_mask is None:
+        base, beta = torch.empty(query.shape[0], query.shape[1], key.shape[1], dtype=query.dtype, device=query.device), 0
+    else:
+        base, beta = attention_mask, 1
+    scores = torch.baddbmm(base, query, key.transpose(-1, -2), beta=beta, alpha=attn.scale)
+    if attn.upcast_softmax:
+        scores = scores.float()
+    return scores.to(query.dtype)
 
 
 class _RegionProcessor:
@@ -243,8 +296,11 @@ class _RegionProcessor:
             batch_size, channel, height, width = hidden_states.shape
             hidden_states = hidden_states.view(batch_size, channel, height * width).transpose(1, 2)
         is_xattn = encoder_hidden_states is not None and region_prompt is not None
+        mask3 = None
         if attention_mask is not None:
-            raise NotImplementedError("attention masks are not on the hot path (app.py never passes one)")
+            # reference :144 / :448-452: [B, 1|L, S_mask] -> padded to the key length and repeated per head -> [B*H, 1|L, S]
+            kv_len = hidden_states.shape[1] if encoder_hidden_states is None else encoder_hidden_states.shape[1]
+            mask3 = attn.prepare_attention_mask(attention_mask, kv_len, hidden_states.shape[0])
         if attn.group_norm is not None:
             hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
         is_self = encoder_hidden_states is None
@@ -304,8 +360,22 @@ class _RegionProcessor:
             groups = region_prompt.get("n_std_groups", self.n_std_groups)
             pre = region_prompt.get("compressed")                           # the pipeline's static (ids, rows) buffers
             comp = pre.get(img_sequence_length) if isinstance(pre, dict) else (False if pre is False else None)
+            if mask3 is not None and not self.honours_attn_scale:
+                # AttnProcessor2_0 hands the [B, H, ., S] view of the mask to scaled_dot_product_attention_regionstate, whose
+                # in-place `attn_bias += attn_mask` into an [L, S] tensor torch refuses for any 4-D mask (:89): the
+                # reference raises here - so does this (same exception type)
+                torch.zeros(L, S, dtype=q4.dtype, device=q4.device).add_(mask3.view(B, H, -1, S))
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
-                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp)
+                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp, mask=mask3)
+        elif mask3 is not None:
+            # no region table: plain masked attention (:483-485 / :182-186) - the mask is the forward kernel's final bias when
+            # the keys fit it, else the library's SDPA
+            if S <= _KERNEL_MAX_KEYS and q4.dtype == torch.float16 and d % 8 == 0 and d <= 160:
+                bias = torch.broadcast_to(mask3.float(), (B * H, L, S)).contiguous()
+                out = ops.region_xattn(q4, k4, v4, bias, 1.0, layout="blhd", scale=sc, bias_is_final=True, ref_fp16_rounding=False)
+            else:
+                out = F.scaled_dot_product_attention(q4.transpose(1, 2), k4.transpose(1, 2), v4.transpose(1, 2),
+                                                     attn_mask=mask3.view(B, H, -1, S).to(q4.dtype), scale=sc).transpose(1, 2).contiguous()
         elif not is_self:
             if S > _KERNEL_MAX_KEYS and q4.dtype == torch.float16 and d % 8 == 0 and d <= 160:
                 out = ops.self_attention(q4, k4, v4, scale=sc)      # long prompt without a region table: the flash kernel (S != L)

@@ -372,9 +372,19 @@ class Attention(nn.Module):
         return self.processor
 
     def prepare_attention_mask(self, attention_mask, target_length, batch_size, out_dim=3):
+        """diffusers 0.27.2 `Attention.prepare_attention_mask` [recalled; un-vendored: parity unpinned]: a mask shorter or longer
+        than the key length is zero-padded by target_length, then repeated per head: [B, 1|L, S] -> [B*heads, 1|L, S]
+        (out_dim 3) or [B, heads, 1|L, S] (out_dim 4)."""
         if attention_mask is None:
             return None
-        raise NotImplementedError("additive attention masks are not on the hot path (never passed by app.py)")
+        if attention_mask.shape[-1] != target_length:
+            attention_mask = F.pad(attention_mask, (0, target_length), value=0.0)
+        if out_dim == 3:
+            if attention_mask.shape[0] < batch_size * self.heads:
+                attention_mask = attention_mask.repeat_interleave(self.heads, dim=0)
+        elif out_dim == 4:
+            attention_mask = attention_mask.unsqueeze(1).repeat_interleave(self.heads, dim=1)
+        return attention_mask
 
     def head_to_batch_dim(self, t, out_dim=3):
         b, n, c = t.shape

@@ -183,9 +183,10 @@ def region_xattn_packed(q, packed_kv, S, region=None, sigma=1.0, *, n_std_groups
     return out
 
 
-def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp16_rounding=True):
-    """std of scale*q.k^T per std group (dsc_region_xattn_std) -> fp32 CUDA tensor [n_std_groups]."""
-    _require_gpu(q, k)
+def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp16_rounding=True, mask=None):
+    """std of scale*q.k^T (+ mask) per std group (dsc_region_xattn_std[_masked]) -> fp32 CUDA tensor [n_std_groups].
+    mask: additive fp32 CUDA tensor broadcastable to [Bc*H, L, S] (shapes [L, S], [1, S], [Bc*H, 1, S], [Bc*H, L, S], ...)."""
+    _require_gpu(q, k, mask)
     lib = _lib.load_library()
     lay = "bhld" if layout == "bhld" else "blc"
     qs, (Bc, H, L, d) = _blhd_strides(q, lay)
@@ -193,12 +194,26 @@ def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp1
     out = torch.empty(n_std_groups, dtype=torch.float32, device=q.device)
     nbytes = lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups)
     ws = _workspace(q.device, nbytes)
-    rc = lib.dsc_region_xattn_std(
+    flags = FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0
+    if mask is None:
+        rc = lib.dsc_region_xattn_std(
+            ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()), Bc, H, L, S, d, n_std_groups,
+            _i64x3(*qs), _i64x3(*ks), float(scale) if scale else 0.0, 0, flags, ctypes.c_void_p(out.data_ptr()),
+            ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _stream_ptr(q))
+        _lib.check(rc, "dsc_region_xattn_std")
+        return out
+    m3 = mask.float()
+    while m3.dim() < 3:
+        m3 = m3.unsqueeze(0)
+    if m3.dim() != 3 or m3.shape[2] != S or m3.shape[1] not in (1, L) or m3.shape[0] not in (1, Bc * H):
+        raise ValueError(f"mask {tuple(mask.shape)} does not broadcast to [{Bc * H}, {L}, {S}]")
+    m3 = m3.contiguous()
+    ms = (ctypes.c_int64 * 2)(0 if m3.shape[0] == 1 else m3.stride(0), 0 if m3.shape[1] == 1 else m3.stride(1))
+    rc = lib.dsc_region_xattn_std_masked(
         ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()), Bc, H, L, S, d, n_std_groups,
-        _i64x3(*qs), _i64x3(*ks), float(scale) if scale else 0.0, 0,
-        FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0, ctypes.c_void_p(out.data_ptr()),
-        ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _stream_ptr(q))
-    _lib.check(rc, "dsc_region_xattn_std")
+        _i64x3(*qs), _i64x3(*ks), float(scale) if scale else 0.0, 0, flags, ctypes.c_void_p(m3.data_ptr()), ms,
+        ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()), ws.numel() * 8, _stream_ptr(q))
+    _lib.check(rc, "dsc_region_xattn_std_masked")
     return out
 
 

@@ -100,6 +100,18 @@ int dsc_region_xattn_std(const void* q, const void* k,
                          const int64_t q_strides[3], const int64_t k_strides[3], float scale,
                          int dtype, unsigned flags, float* std_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * The same with an additive attention mask inside the statistics - reference attention_modify.py:85-95 adds `attn_mask`
+ * (float) to the scaled scores BEFORE weight_func sees them, so the std is over scale * q.k^T + mask; likewise
+ * `get_attention_scores(attn, query, key, attention_mask)` (:39-70, baddbmm with beta = 1) on the AttnProcessor path
+ * (:144,166).  mask: fp32, element (b * H + h, l, s) at mask[bh * mask_strides[0] + l * mask_strides[1] + s]; a stride of 0
+ * broadcasts that dimension (an [L, S] mask: strides {0, S}; a [B*H, 1, S] one: {S, 0}).  NULL = dsc_region_xattn_std.
+ */
+int dsc_region_xattn_std_masked(const void* q, const void* k,
+                                int Bc, int H, int L, int S, int d, int n_std_groups,
+                                const int64_t q_strides[3], const int64_t k_strides[3], float scale,
+                                int dtype, unsigned flags, const float* mask, const int64_t mask_strides[2],
+                                float* std_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Prepared-operand path of the region cross-attention (the one the pipeline uses).

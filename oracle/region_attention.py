@@ -65,7 +65,8 @@ def region_attention(q, k, v, w, sigma, scale=None, attn_mask=None, n_std_groups
     return f(p @ v)                                                 # :103
 
 
-def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain, ip_branch=None):
+def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain, ip_branch=None,
+                 attention_mask=None):
     residual = hidden_states                                        # :425
     img_sequence_length = hidden_states.shape[1]                    # :427 (dim 1 also for 4-D input)
     input_ndim = hidden_states.ndim
@@ -82,11 +83,12 @@ def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core
     qh = query.view(B, -1, H, d).transpose(1, 2)                    # :471-474
     kh = key.view(B, -1, H, d).transpose(1, 2)
     vh = value.view(B, -1, H, d).transpose(1, 2)
+    mk = {} if attention_mask is None else {"mask": attention_mask}   # the processors that take one pass it on (:144, :448-452)
     if is_xattn and isinstance(region_prompt["region_state"], dict):           # :479
         w = region_prompt["region_state"][img_sequence_length]     # KeyError if L not in the table (:481)
-        o = core_region(qh, kh, vh, w, region_prompt["sigma"], region_prompt["weight_func"])
+        o = core_region(qh, kh, vh, w, region_prompt["sigma"], region_prompt["weight_func"], **mk)
     else:
-        o = core_plain(qh, kh, vh)
+        o = core_plain(qh, kh, vh, **mk)
     o = o.transpose(1, 2).reshape(B, -1, H * d)                     # :487
     if ip_branch is not None:
         o = ip_branch(o, qh, B, H, d)                               # :649-683 / :354-384: before the out projection
@@ -98,38 +100,56 @@ def _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core
     return o / attn.rescale_output_factor                           # :501
 
 
-def attn_processor2_0(attn, hidden_states, encoder_hidden_states=None, region_prompt=None, n_std_groups=1):
-    """AttnProcessor2_0.__call__ (:414-503); scale = 1/sqrt(d) on both branches (:77, SDPA default)."""
-    def core_region(q, k, v, w, sigma, weight_func):
+def attn_processor2_0(attn, hidden_states, encoder_hidden_states=None, region_prompt=None, n_std_groups=1, attention_mask=None):
+    """AttnProcessor2_0.__call__ (:414-503); scale = 1/sqrt(d) on both branches (:77, SDPA default).  attention_mask: what
+    `attn.prepare_attention_mask` returned, [B*H, 1|L, S]; viewed [B, H, ., S] (:448-452).  With a region table that 4-D
+    mask meets the in-place `attn_bias += attn_mask` into an [L, S] tensor (:89), which torch refuses: RuntimeError, as in
+    the reference (tests/golden/attention_masks.npz p2/raises)."""
+    def core_region(q, k, v, w, sigma, weight_func, mask=None):
         d = q.shape[-1]
         a = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(d))
         Bc, H, L, S = a.shape
+        if mask is not None:
+            bias = torch.zeros(L, S, dtype=q.dtype)
+            bias += mask.view(Bc, H, -1, S)                         # :89 - raises for any 4-D mask
+            a = a + bias
         flat = a.reshape(-1, L, S)                                  # :94
         cw = weight_func(w, sigma, flat)                            # :95
         flat = flat + torch.repeat_interleave(cw, flat.shape[0] // cw.shape[0], dim=0)
         return torch.softmax(flat.reshape(Bc, H, L, S), dim=-1) @ v
 
-    def core_plain(q, k, v):
+    def core_plain(q, k, v, mask=None):
         d = q.shape[-1]
-        return torch.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(d)), dim=-1) @ v   # :483-485
+        a = (q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(d))
+        if mask is not None:
+            a = a + mask.view(a.shape[0], a.shape[1], -1, a.shape[-1])
+        return torch.softmax(a, dim=-1) @ v                         # :483-485
 
-    return _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain)
+    return _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain,
+                        attention_mask=attention_mask)
 
 
-def attn_processor(attn, hidden_states, encoder_hidden_states=None, region_prompt=None):
-    """AttnProcessor.__call__ (:106-207): same math through baddbmm/bmm with alpha = attn.scale (:57-63)."""
-    def core_region(q, k, v, w, sigma, weight_func):
+def attn_processor(attn, hidden_states, encoder_hidden_states=None, region_prompt=None, attention_mask=None):
+    """AttnProcessor.__call__ (:106-207): same math through baddbmm/bmm with alpha = attn.scale (:57-63); the attention mask
+    ([B*H, 1|L, S]) is baddbmm's additive input (beta = 1, :52-63), so weight_func's std sees the masked scores (:166-167)."""
+    def core_region(q, k, v, w, sigma, weight_func, mask=None):
         a = (q @ k.transpose(-2, -1)) * attn.scale                  # get_attention_scores :57-63
         Bc, H, L, S = a.shape
         flat = a.reshape(-1, L, S)
+        if mask is not None:
+            flat = flat + mask
         cw = weight_func(w, sigma, flat)                            # :167
         flat = flat + torch.repeat_interleave(cw, flat.shape[0] // cw.shape[0], dim=0)
         return torch.softmax(flat.reshape(Bc, H, L, S), dim=-1) @ v            # :173-175
 
-    def core_plain(q, k, v):
-        return torch.softmax((q @ k.transpose(-2, -1)) * attn.scale, dim=-1) @ v   # :187-188
+    def core_plain(q, k, v, mask=None):
+        a = (q @ k.transpose(-2, -1)) * attn.scale
+        if mask is not None:
+            a = (a.reshape(-1, a.shape[-2], a.shape[-1]) + mask).reshape(a.shape)
+        return torch.softmax(a, dim=-1) @ v                         # :187-188
 
-    return _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain)
+    return _proc_common(attn, hidden_states, encoder_hidden_states, region_prompt, core_region, core_plain,
+                        attention_mask=attention_mask)
 
 
 # ----------------------------------------------------------------------------- IP-Adapter processors (SURVEY.md 8f rank 2)

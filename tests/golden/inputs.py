@@ -43,6 +43,20 @@ def attn_inputs(name, Bc, H, L, S, d, Bw=None, nrows=16):
     return {"q": q, "k": k, "v": v, "w": w, "rows": rows}
 
 
+def mask_inputs(L=256, S=77, BH=16):
+    """additive attention masks for the region path (attention_modify.py:85-91,144): fp16-representable, a few strongly
+    negative entries; `ls` broadcasts into [L, S], `s1` is [1, S], `bh1s` is the [B*H, 1, S] shape prepare_attention_mask
+    returns, `b4` a 4-D mask that the reference's in-place add refuses"""
+    rng = _rng("masks")
+    m = {"ls": _h(rng.standard_normal((L, S)) * 1.5), "s1": _h(rng.standard_normal((1, S)) * 2.0),
+         "bh1s": _h(rng.standard_normal((BH, 1, S)) * 1.5)}
+    m["ls"][:, 70:] = -8.0
+    m["s1"][:, 5] = -20.0
+    m["bh1s"][:, :, 60:] = -6.0
+    m["bool"] = rng.random((L, S)) < 0.7
+    return m
+
+
 def proc_inputs():
     rng = _rng("proc")
     C, H, ctx, L, S = 160, 4, 96, 64, 77

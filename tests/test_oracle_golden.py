@@ -153,6 +153,34 @@ def test_ip_adapter_processors(pname, fn):
     np.testing.assert_allclose(o0, ref0, atol=3e-5, rtol=0)
 
 
+def test_attention_masks():
+    """the oracle's mask branches against outputs of the reference's own functions (tests/golden/make_golden_masks.py)"""
+    from inputs import mask_inputs
+    g = load("attention_masks.npz")
+    x = attn_inputs("L256_d160", Bc=2, H=8, L=256, S=77, d=160)
+    q, k, v, w = (torch.from_numpy(x[n]) for n in ("q", "k", "v", "w"))
+    m = mask_inputs()
+    rows = x["rows"]
+    for name in ("ls", "s1"):
+        o = ra.region_attention(q, k, v, w, 3.25, attn_mask=torch.from_numpy(m[name]))
+        np.testing.assert_allclose(o[:, :, rows, :].numpy(), g["a1/" + name], atol=1e-5, rtol=0)
+    # the bool branch never reaches the scores (:86-87 only rewrites the mask) and a 4-D float mask cannot be added in place
+    assert bool(g["a1/bool_equals_unmasked"]) and bool(g["a1/bool_mask_all_true_afterwards"]) and bool(g["a1/b4_raises"])
+    np.testing.assert_allclose(ra.region_attention(q, k, v, w, 3.25)[:, :, rows, :].numpy(), g["a1/bool"], atol=1e-5, rtol=0)
+    p = proc_inputs()
+    L, S, H = p["L"], p["S"], p["H"]
+    hs, enc = torch.from_numpy(p["hidden"]), torch.from_numpy(p["enc"])
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": torch.tensor(2.5), "weight_func": ra.default_weight_func}
+    mp = torch.from_numpy(mask_inputs(L=L, S=S, BH=2 * H)["bh1s"])
+    attn = DuckAttn(p)
+    np.testing.assert_allclose(ra.attn_processor(attn, hs, enc, rp, attention_mask=mp).numpy(), g["p1/cross_region_mask"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(ra.attn_processor2_0(attn, hs, enc, None, attention_mask=mp).numpy(), g["p2/cross_noregion_mask"],
+                               atol=2e-5, rtol=0)
+    assert bool(g["p2/raises"])
+    with pytest.raises(RuntimeError):
+        ra.attn_processor2_0(attn, hs, enc, rp, attention_mask=mp)
+
+
 def test_processor_variants_agree():
     """a3 and a4 are the same function of their inputs (max diff 0.0 in fp32)."""
     g = load("processors.npz")

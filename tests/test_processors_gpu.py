@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from inputs import attn_inputs, ip_inputs, proc_inputs
+from inputs import attn_inputs, ip_inputs, mask_inputs, proc_inputs
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
@@ -138,8 +138,55 @@ def test_processors_against_reference_goldens(mods, pname):
         check(proc(DuckAttn(p, True, 2.0), hs4, encoder_hidden_states=enc, region_prompt=rp4), "cross_region_4d_res")
         with pytest.raises(KeyError):
             proc(attn, hs, encoder_hidden_states=enc, region_prompt=dict(rp, region_state={L + 1: torch.from_numpy(p["w"])}))
-        with pytest.raises(NotImplementedError):
-            proc(attn, hs, encoder_hidden_states=enc, attention_mask=torch.zeros(1), region_prompt=rp)
+
+
+def test_attention_masks_against_reference_goldens(mods):
+    """additive / boolean attention masks on the region path (reference attention_modify.py:85-91,144,448-452) against outputs
+    of the reference's own functions (tests/golden/attention_masks.npz): the float mask enters the statistics
+    (dsc_region_xattn_std_masked), the bool mask only rewrites itself, 4-D masks raise as in the reference."""
+    ops, am = mods
+    g = np.load(os.path.join(G, "attention_masks.npz"))
+    x = attn_inputs("L256_d160", Bc=2, H=8, L=256, S=77, d=160)
+    q, k, v = (torch.from_numpy(x[n]).half().cuda() for n in ("q", "k", "v"))
+    w = torch.from_numpy(x["w"])
+    m = mask_inputs()
+    wf = lambda w_, s_, qk: w_ * s_ * qk.std()                      # noqa: E731
+    call = lambda mask: am.scaled_dot_product_attention_regionstate(q, k, v, attn_mask=mask, weight_func=wf,  # noqa: E731
+                                                                    region_state=w, sigma=torch.tensor(3.25))
+    rows = x["rows"]
+    for name in ("ls", "s1"):
+        out = call(torch.from_numpy(m[name]).half().cuda())
+        err = np.abs(out[:, :, rows, :].float().cpu().numpy() - g["a1/" + name])
+        # fp16-rounding emulation on, |scores + mask + bias| reaches 16..32 where one fp16 ulp is 1.56e-2: one ulp of a logit
+        assert err.max() < 1.6e-2 and err.mean() < 1e-3, (name, err.max(), err.mean())
+    # the statistics really include the mask: the std of the masked scores differs from the unmasked one
+    s0 = ops.region_xattn_std(q, k).item()
+    s1 = ops.region_xattn_std(q, k, mask=torch.from_numpy(m["ls"]).cuda()).item()
+    a = (q.float() @ k.float().transpose(-2, -1)) / math.sqrt(160) + torch.from_numpy(m["ls"]).cuda()
+    assert abs(s1 - a.std().item()) < 2e-3 * s1 and abs(s1 - s0) > 0.05
+    mb = torch.from_numpy(m["bool"]).cuda()
+    out_b = call(mb)
+    assert bool(mb.all())                                           # :86-87 turned every element True
+    assert torch.equal(out_b, call(None))
+    assert np.abs(out_b[:, :, rows, :].float().cpu().numpy() - g["a1/bool"]).max() < 8e-3
+    with pytest.raises(RuntimeError):
+        call(torch.zeros(2, 8, 1, 77, device="cuda", dtype=torch.half))
+    # processors: AttnProcessor adds the [B*H, 1, S] mask inside get_attention_scores (std over the masked scores);
+    # AttnProcessor2_0 raises with a region table and runs plain masked attention without one
+    p = proc_inputs()
+    L, S, H = p["L"], p["S"], p["H"]
+    hs, enc = torch.from_numpy(p["hidden"]).half().cuda(), torch.from_numpy(p["enc"]).half().cuda()
+    rp = {"region_state": {L: torch.from_numpy(p["w"])}, "sigma": torch.tensor(2.5), "weight_func": wf}
+    mp = torch.from_numpy(mask_inputs(L=L, S=S, BH=2 * H)["bh1s"]).half().cuda()
+    attn = DuckAttn(p)
+    attn.prepare_attention_mask = lambda mask, *a_, **k_: mask     # the golden's duck-typed attn returns the mask as is
+    with torch.no_grad():
+        o1 = am.AttnProcessor()(attn, hs, encoder_hidden_states=enc, attention_mask=mp, region_prompt=rp)
+        assert np.abs(o1.float().cpu().numpy() - g["p1/cross_region_mask"]).max() < TOL
+        o2 = am.AttnProcessor2_0()(attn, hs, encoder_hidden_states=enc, attention_mask=mp)
+        assert np.abs(o2.float().cpu().numpy() - g["p2/cross_noregion_mask"]).max() < TOL
+        with pytest.raises(RuntimeError):
+            am.AttnProcessor2_0()(attn, hs, encoder_hidden_states=enc, attention_mask=mp, region_prompt=rp)
 
 
 def test_custom_weight_func_takes_the_generic_path(mods):

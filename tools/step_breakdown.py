@@ -36,6 +36,7 @@ def main(paths, verbose):
             continue
         fam = collections.defaultdict(lambda: [0, 0])
         lib = collections.defaultdict(lambda: [0, 0])
+        per = collections.defaultdict(lambda: [0, 0])
         wall = n = 0
         for a, b in zip(marks[-21:-1], marks[-20:]):
             n += 1
@@ -45,6 +46,11 @@ def main(paths, verbose):
                 f = fam[family(r["Kernel_Name"])]
                 f[0] += d
                 f[1] += 1
+                short = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
+                short = re.sub(r"\(.*", "", short)[:60] if not short.startswith("Cijk") else "Cijk " + re.search(r"MT\d+x\d+x\d+", short).group(0)
+                pk = per[short + " grid " + r["Grid_Size_X"] + "x" + r.get("Grid_Size_Y", "1") + "x" + r.get("Grid_Size_Z", "1")]
+                pk[0] += d
+                pk[1] += 1
                 if r["Kernel_Name"].startswith("Cijk"):
                     k = lib[re.search(r"MT\d+x\d+x\d+", r["Kernel_Name"]).group(0) + " grid " + r["Grid_Size_X"]]
                     k[0] += d
@@ -54,11 +60,14 @@ def main(paths, verbose):
               % (path, n, total / n / 1e6, wall / n / 1e6, sum(v[1] for v in fam.values()) / n))
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0]):
             print("   %-12s %6.3f ms %6.1f launches" % (k, v[0] / n / 1e6, v[1] / n))
-        if verbose:
+        if verbose > 1:
+            for k, v in sorted(per.items(), key=lambda kv: -kv[1][0]):
+                print("      %-90s %7.1f us / step %5.1f x %6.1f us" % (k, v[0] / n / 1e3, v[1] / n, v[0] / v[1] / 1e3))
+        elif verbose:
             for k, v in sorted(lib.items(), key=lambda kv: -kv[1][0]):
                 print("      %-30s %7.1f us / step %5.1f x %6.1f us" % (k, v[0] / n / 1e3, v[1] / n, v[0] / v[1] / 1e3))
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "-v"]
-    main(args, "-v" in sys.argv)
+    args = [a for a in sys.argv[1:] if a not in ("-v", "-vv")]
+    main(args, 2 if "-vv" in sys.argv else (1 if "-v" in sys.argv else 0))
