@@ -7,6 +7,8 @@ packed region cross-attention) - the toy-width tests in test_unet_pipeline_gpu.p
   * configs[2] (512x512, 4 masks, 8 images per GPU -> Bc = 16, n_std_groups = 8): image i of the batch equals the
     single-image run (std group = rows {i, 8 + i}), one image against the oracle, and the region
     cross-attention of every level at Bc = 16 against the oracle on the layer's own q / k / v.
+  * configs[3] (768x768, batch 8 on one GPU) and configs[4] (SDXL-shape UNet at 1024x1024, 2 images per GPU): the batch
+    equals the per-image runs (independent std groups); SDXL's region cross-attention layers against the oracle.
   * generation-to-generation state: tables with more than 32 distinct rows (not compressible) and custom weight_func
     closures must never replay an earlier generation's masks / captured values.
 Tolerances are relative to the oracle's output range and written where they are asserted.
@@ -139,6 +141,8 @@ def test_config3_eight_images_four_masks(sd15):
     rs8 = {L: w.repeat(n, 1, 1) for L, w in rs1.items()}                    # encode_region_map's .repeat(num_images, 1, 1) (:122)
     got8 = _fused(sd15, lats, sig, text8, rs8, 3)
     assert torch.isfinite(got8).all()
+    full = pipe.txt2img(None, latents=lats.cuda(), num_images_per_prompt=n, **kw)[0]      # all 25 steps through txt2img itself
+    assert full.shape == (n, 4, 64, 64) and torch.isfinite(full).all()
     # (2) image i of the batch == the single-image run (its std group is rows {i, 8 + i}); different launch geometry
     # (grids, split-K counts) -> equal to rounding: 2e-3 of the latent range
     text1 = torch.cat([emb[0:1], emb[1:2]])
@@ -257,3 +261,91 @@ def test_custom_weight_func_closures_are_not_shared_between_generations():
     scale = fresh_three.abs().max().item()
     assert (one - three).abs().max().item() > 1e-3 * scale
     assert (three - fresh_three).abs().max().item() < 2e-2 * scale
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] / [4] at their per-GPU batch
+def test_config4_768_eight_images(sd15):
+    """BASELINE configs[3]: SD1.5 at 768x768 (L = 9216 / 2304 / 576 / 144), 2 region masks, batch 8 on one GPU (Bc = 16,
+    n_std_groups = 8): two fused steps, finite, and image i of the batch equals its single-image run to 2e-3 of the latent
+    range (the oracle comparison of this geometry is test_config4_sd15_768_step's, layer by layer)."""
+    emb, ids, state, _ = _inputs(768, 2)
+    rs1 = _region_tables(sd15.pipe, state, 768, ids)
+    assert sorted(rs1) == [144, 576, 2304, 9216]
+    n = 8
+    lats = torch.stack([_latent(i, 96) for i in range(n)]).half()
+    sig = sd15.pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
+    text8 = torch.cat([emb[0:1].repeat(n, 1, 1), emb[1:2].repeat(n, 1, 1)])
+    rs8 = {L: w.repeat(n, 1, 1) for L, w in rs1.items()}
+    got8 = _fused(sd15, lats, sig, text8, rs8, 2)
+    assert got8.shape == (n, 4, 96, 96) and torch.isfinite(got8).all()
+    scale = got8.abs().max().item()
+    text1 = torch.cat([emb[0:1], emb[1:2]])
+    for i in (0, 6):
+        single = _fused(sd15, lats[i:i + 1], sig, text1, rs1, 2)
+        d = (single[0] - got8[i]).abs().max().item()
+        print(f"768x768 image {i}: batch-of-8 vs single {d:.3e} (range {scale:.2f})")
+        assert d < 2e-3 * scale, (i, d, scale)
+
+
+def test_config5_sdxl_two_images_per_gpu():
+    """BASELINE configs[4]: SDXL-base UNet geometry at 1024x1024, 16 images over 8 GPUs = 2 per GPU (Bc = 4, n_std_groups = 2).
+    One CFG forward: each image's rows equal that image's own Bc = 2 forward (independent std groups), and the region
+    cross-attention of both attention levels (L = 4096, 10 heads; L = 1024, 20 heads; d = 64, context 2048) is checked
+    against the oracle on the layer's own q / k / v with the per-image groups.  (The reference has no SDXL pipeline,
+    SURVEY.md 8d: this extrapolates the same processor contract.)"""
+    from diffusionspatialcontrol_amd.modules.attention_modify import AttnProcessor2_0
+    from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
+    torch.manual_seed(0)
+    with torch.device("cuda"):
+        unet = UNet2DConditionModel(UNetConfig.sdxl_base()).half().eval()
+    g = torch.Generator().manual_seed(6)
+    n = 2
+    x1 = torch.randn(n, 4, 128, 128, generator=g).half()
+    enc1 = torch.randn(2, 77, 2048, generator=g).half()
+    x = torch.cat([x1, x1]).cuda()                                          # rows [u_0, u_1, c_0, c_1]
+    enc = torch.cat([enc1[0:1].repeat(n, 1, 1), enc1[1:2].repeat(n, 1, 1)]).cuda()
+    t = torch.full((2 * n,), 400.0, device="cuda")
+    rs = {}
+    gg = torch.Generator().manual_seed(2)
+    for L in (16384, 4096, 1024):
+        w = torch.zeros(2, L, 77)
+        w[:, torch.rand(L, generator=gg) < 0.3, 2:4] = 0.5
+        w[:, torch.rand(L, generator=gg) < 0.3, 4:6] += 0.5
+        rs[L] = w
+    rs_n = {L: w.repeat(n, 1, 1) for L, w in rs.items()}
+    wf = lambda w_, s_, qk: w_ * s_ * qk.std()                                # noqa: E731
+    seen = {}
+
+    class Recorder(AttnProcessor2_0):
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, region_prompt=None):
+            out = super().__call__(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, region_prompt=region_prompt)
+            L = hidden_states.shape[1]
+            if encoder_hidden_states is not None and L not in seen and hidden_states.shape[0] == 2 * n:
+                q = attn.to_q(hidden_states)
+                k, v = attn.to_k(encoder_hidden_states), attn.to_v(encoder_hidden_states)
+                B, _, C = q.shape
+                H = attn.heads
+                seen[L] = (q.view(B, L, H, C // H), k.view(B, 77, H, C // H), v.view(B, 77, H, C // H), attn.to_out[0], out)
+            return out
+
+    unet.set_attn_processor(Recorder())
+    with torch.no_grad():
+        rp = {"region_state": rs_n, "sigma": torch.tensor([4.0], device="cuda"), "weight_func": wf, "n_std_groups": n}
+        y = unet(x, t, enc, cross_attention_kwargs={"region_prompt": rp}).sample
+        assert y.shape == (2 * n, 4, 128, 128) and torch.isfinite(y).all()
+        scale = y.float().abs().max().item()
+        for i in range(n):
+            rp1 = {"region_state": rs, "sigma": torch.tensor([4.0], device="cuda"), "weight_func": wf}
+            y1 = unet(x[[i, n + i]], t[:2], enc[[i, n + i]], cross_attention_kwargs={"region_prompt": rp1}).sample
+            dmax = (y1.float() - y[[i, n + i]].float()).abs().max().item()
+            print(f"SDXL image {i}: rows of the Bc=4 forward vs its own Bc=2 forward {dmax:.3e} (range {scale:.2f})")
+            assert dmax < 4e-3 * scale, (i, dmax, scale)
+    assert sorted(seen) == [1024, 4096]
+    for L, (q, k, v, to_out, got) in seen.items():
+        for i in range(n):
+            rows = [i, n + i]
+            qc, kc, vc = (z[rows].float().cpu().transpose(1, 2) for z in (q, k, v))
+            exp = ra.region_attention(qc, kc, vc, rs_n[L][rows], 4.0).transpose(1, 2).reshape(2, L, -1)
+            exp = torch.nn.functional.linear(exp, to_out.weight.float().cpu(), to_out.bias.float().cpu())
+            err = (got[rows].float().cpu() - exp).abs()
+            assert err.max().item() < 8e-3 * max(1.0, exp.abs().max().item()), (L, i, err.max().item())
