@@ -398,23 +398,26 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     if (dbg && lane == 0)
         for (int i = 0; i < 6; ++i) p.stamps[i] = seg[i];
 
-    // ---- epilogue: O / l, fp16, out[b, q, h, :]
+    // ---- epilogue: O / l, fp16, out[b, q, h, :].  The lane id is re-derived here (v_mbcnt) so that nothing the epilogue
+    // addresses with has to stay live - or be spilled - across the tile loop of the 168-register kernels
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int r_e = lane_e & 31, hh_e = lane_e >> 5;
     float l_tot;
     if (ONES) {
         // channel 16 NK of O^T is sum_s p: row tile DM-1, element 8 of the hh = 0 lanes (16 = (i & 3) + 8 (i >> 2) + 4 hh)
-        l_tot = __shfl(o[DM - 1][8], r, 64);                 // lane r (hh = 0) holds it for query row r
+        l_tot = __shfl(o[DM - 1][8], r_e, 64);               // lane r (hh = 0) holds it for query row r
     } else {
         l_tot = l_run + __shfl_xor(l_run, 32, 64);
     }
     const float inv = 1.f / l_tot;
-    const int qrow = q0 + r;
+    const int qrow = q0 + r_e;
     if (qrow < p.L) {
         half_t* op = p.out + b * p.osb + h * p.osh + (long long)qrow * p.osl;
 #pragma unroll
         for (int dm = 0; dm < DM; ++dm)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                const int dd0 = 32 * dm + 8 * g4 + 4 * hh_e;
                 if (dd0 < p.d) {
                     const h4_t ov = {(half_t)(o[dm][4 * g4] * inv), (half_t)(o[dm][4 * g4 + 1] * inv),
                                      (half_t)(o[dm][4 * g4 + 2] * inv), (half_t)(o[dm][4 * g4 + 3] * inv)};
@@ -441,6 +444,11 @@ int launch(const SaParams& p0, hipStream_t st) {
 }
 
 int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant): 0 = auto
+// Not built (examined, round 2): two query tiles per wave (64 rows: half the LDS reads and tile bytes per MFMA).  It needs
+// ~300 registers.  With a loader wave two waves share a SIMD, i.e. 256 registers each: 33 spills.  Without one, at 512, the
+// compiler parks the accumulators in AGPRs and copies them around every branch (~290 v_accvgpr per tile), and the DMA must
+// then be issued by the computing waves, where every ds_read_b64_tr_b16 behind a pending DMA gets a compiler-inserted
+// vmcnt(0).
 
 // Tilings (dsc_debug_set_self_attn_variant forces one; 0 = choose from the shape):
 //   1  4 waves of 32 query rows, every wave issues its share of the DMA
@@ -448,6 +456,7 @@ int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant
 //   3  4 waves under a three-waves-per-SIMD register budget (the configuration that faulted with register-staged tiles)
 //   4 / 5  4 / 8 computing waves + 1 loader wave        6 / 7  4 / 8 computing waves + 2 loader waves
 //   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13); 11 / 12  as 1 / 2 with it
+//   15 / 16  2 / 4 computing waves + 4 loader waves (any head dim)
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
     constexpr int MW = NK <= 5 ? 2 : 1;                       // waves per SIMD the registers allow: 256 / 512 per wave
@@ -476,6 +485,14 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return compact ? launch<3, 8, 2, 5, 1>(p, st) : launch<3, 8, 2, 0, 1>(p, st);
         if (v == 0 && compact && wg4 >= 256) return launch<3, 4, 2, 5, 0>(p, st);
     }
+    // 15 / 16: 2 / 4 computing waves + FOUR loader waves, any head dim - the small-L levels (d = 80 at 32x32, d = 160 at 16x16)
+    // have too few query rows to share a tile among many waves, so without loaders each of the 2 computing waves issues 10-20
+    // DMA pieces per tile (1300-2700 cycles against 700-1300 of MFMA)
+    // (d = 160 does not fit the 256 registers that six waves per workgroup leave each wave: two loaders, four waves, 512)
+    if (v == 15) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 2, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
+    if (v == 16) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 4, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
+    // measured (tools/mb_sa.py): d = 80 @ L = 1024 21.4 -> 15.1 us, d = 160 @ L = 256 16.5 -> 11.9 us, @ L = 64 8.6 -> 6.8 us
+    if (v == 0 && NK >= 5 && wg4 < 256) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 2, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
     if (NK == 5 && ((v == 0 && wg8 >= 512) || v == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
     if (NK <= 4 && v == 2) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
     if (wg4 >= 256 || v == 1) return launch<NK, 4, MW>(p, st);
