@@ -206,11 +206,16 @@ def roofline_self_attn(dev, n_img):
     g = torch.Generator().manual_seed(5)
     qkv = torch.randn(Bc, L, 3 * C, generator=g).half().to(dev)
     q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+    # the operand layout the pipeline hands the kernel: the fused QKV projection (dsc_linear_qkv_f16) writes K / V head-major
+    # ([2, Bc, H, L, d]; a head's keys contiguous), Q token-major
+    k, v = (t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3) for t in (k, v))
+    q = q.contiguous()
     out = torch.empty(Bc, L, H, d, dtype=torch.half, device=dev)
     us = graph_launch_time_us(lambda: ops.self_attention(q, k, v, out=out), launches=20, replays=5)
     flops = 4.0 * L * L * C * Bc
     tf = flops / (us * 1e-6) / 1e12
-    return {"kernel": "self_attn_fwd<3,4> (flash self-attention, L=4096 C=320 d=40, Bc=%d)" % Bc, "bound": "mfma",
+    return {"kernel": "self_attn_fwd (flash self-attention, L=4096 C=320 d=40, Bc=%d; K/V head-major as the pipeline's QKV "
+                      "projection writes them)" % Bc, "bound": "mfma",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
             "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2)}
 
@@ -509,6 +514,17 @@ def main():
                                   "outputs_finite": finite and all(bool(torch.isfinite(o).all().item()) for o in slot_outs),
                                   "workload": res["config"]["workload"].replace("1 generation(s) in flight", f"{nfl} generation(s) in flight")})
     if res is not None:
+        try:
+            import ctypes
+            from diffusionspatialcontrol_amd import _lib
+            st3 = (ctypes.c_longlong * 3)()
+            _lib.load_library().dsc_linear_lt_stats(st3)
+            res["config"]["library_gemm_algorithms"] = {"shapes": int(st3[0]), "candidates_offered": int(st3[1]),
+                                                        "dropped_needing_workspace": int(st3[2]),
+                                                        "note": "only workspace-free hipBLASLt algorithms are eligible (no stream-K / split-K "
+                                                                "kernels whose workgroups wait on each other): linear_lt.hip"}
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(res), flush=True)
     if dist:
         td.barrier()
