@@ -108,9 +108,15 @@ unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cyc
 // `buffer_load ... lds` per 1-KiB piece; a wave gets ~one piece per 100-200 cycles through: 13 of them cost each of 4 computing
 // waves ~450 of ~1900 cycles per tile when they issued their share themselves).  The computing waves then contain no vector
 // memory instruction between their Q loads and their output stores; all WAVES + NLOAD waves meet at ONE s_barrier per tile.
-template <int NK, int WAVES, int MINW, int D8, int NLOAD>
+//
+// STAGGER (8 computing waves + loaders): the two waves of a SIMD come from ONE workgroup and would run the same phase at the
+// same time - both in their MFMA chains, then both in their exponentials.  Waves 4-7 therefore run P.V one tile late (its
+// V^T fragments and probabilities stay in registers across the barrier), so that while waves 0-3 are in the softmax their SIMD
+// partners are in QK^T, and while the partners are in the softmax waves 0-3 are in P.V.
+template <int NK, int WAVES, int MINW, int D8, int NLOAD, bool STAGGER>
 __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaParams p) {
     constexpr bool LOADER = NLOAD > 0;
+    static_assert(!STAGGER || (LOADER && WAVES == 8 && NK <= 5), "the stagger is for 8 computing waves with loader waves");
     using C = SaCfg<NK, D8>;
     constexpr int DM = C::DM, KP = C::KP, VP = C::VP, KC = C::KC, VC = C::VC;
     constexpr bool ONES = C::ONES;
@@ -263,6 +269,15 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
+    h8_t pf[4];                                              // probabilities of a tile, packed as the P.V B operand
+    h8_t vf[HOIST ? DM : 1][HOIST ? 4 : 1];                  // its V^T fragments (HOIST kernels)
+    const bool late = STAGGER && wave >= 4;                  // wave-uniform
+    auto pv_hoisted = [&]() {
+#pragma unroll
+        for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) o[dm] = mfma_32x32x16(vf[HOIST ? dm : 0][HOIST ? tt : 0], pf[tt], o[dm]);
+    };
     int buf = NBUF - 1;
     for (int t = 0; t < ntiles; ++t) {
         buf = buf + 1 == NBUF ? 0 : buf + 1;                 // t % NBUF
@@ -290,8 +305,11 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
             const h4_t hi = lds_read_tr(a + 8 * VP * 2);
             return h8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         };
+        if (STAGGER && late && t > 0) {                      // the previous tile's P.V, beside the partner wave's QK^T
+            pv_hoisted();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         h8_t kf[HOIST ? 2 : 1][HOIST ? NK : 1];
-        h8_t vf[HOIST ? DM : 1][HOIST ? 4 : 1];
         if constexpr (HOIST) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -359,7 +377,6 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;
         }
-        h8_t pf[4];
         float psum = 0.f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -384,17 +401,22 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
         SA_STAMP(2)
 
         // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels)
+        if constexpr (STAGGER) {
+            if (!late) pv_hoisted();
+        } else {
 #pragma unroll
-        for (int dm = 0; dm < DM; ++dm) {
+            for (int dm = 0; dm < DM; ++dm) {
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const h8_t vfr = HOIST ? vf[HOIST ? dm : 0][HOIST ? tt : 0] : v_frag(dm, tt);
-                o[dm] = mfma_32x32x16(vfr, pf[tt], o[dm]);
+                for (int tt = 0; tt < 4; ++tt) {
+                    const h8_t vfr = HOIST ? vf[HOIST ? dm : 0][HOIST ? tt : 0] : v_frag(dm, tt);
+                    o[dm] = mfma_32x32x16(vfr, pf[tt], o[dm]);
+                }
             }
         }
         if (dbg) asm volatile("" :: "v"(o[0][0]), "v"(o[DM - 1][15]));
         SA_STAMP(3)
     }
+    if (STAGGER && late) pv_hoisted();                       // the last tile's P.V of the late waves
     if (dbg && lane == 0)
         for (int i = 0; i < 6; ++i) p.stamps[i] = seg[i];
 
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     }
 }
 
-template <int NK, int WAVES, int MINW, int D8 = 0, int NLOAD = 0>
+template <int NK, int WAVES, int MINW, int D8 = 0, int NLOAD = 0, bool STAGGER = false>
 int launch(const SaParams& p0, hipStream_t st) {
     SaParams p = p0;
     p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
@@ -435,11 +457,11 @@ int launch(const SaParams& p0, hipStream_t st) {
     const size_t lds = (size_t)SaCfg<NK, D8>::lds_bytes(NLOAD > 0 ? 3 : 2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, MINW, D8, NLOAD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&self_attn_fwd<NK, WAVES, MINW, D8, NLOAD, STAGGER>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    DSC_LAUNCH((self_attn_fwd<NK, WAVES, MINW, D8, NLOAD>), dim3(p.Bc * p.H * p.nqb), dim3(64 * (WAVES + NLOAD)), lds, st, p);
+    DSC_LAUNCH((self_attn_fwd<NK, WAVES, MINW, D8, NLOAD, STAGGER>), dim3(p.Bc * p.H * p.nqb), dim3(64 * (WAVES + NLOAD)), lds, st, p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
@@ -456,6 +478,7 @@ int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant
 //   3  4 waves under a three-waves-per-SIMD register budget (the configuration that faulted with register-staged tiles)
 //   4 / 5  4 / 8 computing waves + 1 loader wave        6 / 7  4 / 8 computing waves + 2 loader waves
 //   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13); 11 / 12  as 1 / 2 with it
+//   13 / 14  8 computing waves + 1 / 2 loader waves, waves 4-7 staggered by one P.V (compact image at d = 40)
 //   15 / 16  2 / 4 computing waves + 4 loader waves (any head dim)
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
@@ -479,10 +502,14 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         if (v == 10 && compact) return launch<3, 8, 2, 5, 1>(p, st);
         if (v == 11 && compact) return launch<3, 4, 2, 5, 0>(p, st);
         if (v == 12 && compact) return launch<3, 8, 2, 5, 0>(p, st);
+        constexpr int NS = NK <= 3 ? NK : 3;                  // (the staggered kernel of NK = 4 spills at 168 registers: not built)
+        if (v == 13) return compact ? launch<3, 8, 2, 5, 1, true>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, true>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
+        if (v == 14) return compact ? launch<3, 8, 2, 5, 2, true>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, true>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
         // measured (tools/mb_sa.py, head-major K / V): at batch 1 (+CFG) the SD1.5 64x64 level offers 256 workgroups of 256
         // query rows - one per CU, 8 computing waves + a loader wave: 64 us against 70 for two 4-wave workgroups per CU
         // that issue their own DMA; at 8 images the 4-wave workgroups win (480 vs 505 us)
-        if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return compact ? launch<3, 8, 2, 5, 1>(p, st) : launch<3, 8, 2, 0, 1>(p, st);
+        // (staggered: 64.0 us against 66.6 for the same kernel with all eight waves in phase)
+        if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return compact ? launch<3, 8, 2, 5, 1, true>(p, st) : launch<3, 8, 2, 0, 2, true>(p, st);
         if (v == 0 && compact && wg4 >= 256) return launch<3, 4, 2, 5, 0>(p, st);
     }
     // 15 / 16: 2 / 4 computing waves + FOUR loader waves, any head dim - the small-L levels (d = 80 at 32x32, d = 160 at 16x16)

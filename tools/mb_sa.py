@@ -25,7 +25,7 @@ for (B, H, L, d) in [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8
     if os.environ.get("HM", "1") == "1":       # head-major K / V, as dsc_linear_qkv_f16 writes them
         k, v = (t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3) for t in (k, v))
     out = torch.empty(B, L, H, d, device=dev, dtype=torch.half)
-    variants = [0, 1, 2] + ([3, 4, 5, 6, 7] if d <= 64 else []) + ([8, 9, 10, 11, 12] if d == 40 else []) + [15, 16]
+    variants = [0, 1, 2] + ([3, 4, 5, 6, 7] if d <= 64 else []) + ([8, 9, 10, 11, 12] if d == 40 else []) + ([13, 14] if d <= 64 else []) + [15, 16]
     best = {v_: 1e9 for v_ in variants}
     for rnd in range(4):                       # interleaved rounds, best of: the clock drifts by ~10 % over a run
         for var in variants:
