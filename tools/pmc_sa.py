@@ -7,6 +7,8 @@ B, H, L, d = 2, 8, 4096, 40
 C = H * d
 qkv = torch.randn(B, L, 3 * C, device=dev).half()
 q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
+k, v = (t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3) for t in (k, v))     # head-major, as dsc_linear_qkv_f16 writes them
+q = q.contiguous()
 x = torch.randn(2, 320, 64, 64, device=dev).half().contiguous(memory_format=torch.channels_last)
 w = (torch.randn(320, 320, 3, 3, device=dev) / 54).half().contiguous(memory_format=torch.channels_last)
 for _ in range(20):
