@@ -80,6 +80,7 @@ _SIGNATURES = {
     "dsc_linear_rows_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 3 + [ctypes.c_int64] * 2 + [ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_linear_ln_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                           [ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_float, _vp, ctypes.c_int, _vp]),
+    "dsc_debug_set_gemm_stages": (None, [ctypes.c_int]),
     "dsc_linear_qkv_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_add_layernorm": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
@@ -112,6 +113,8 @@ def load_library():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    if os.environ.get("DSC_GEMM_STAGES"):                      # A/B switch: K-tile ring depth of the hand-written GEMM (2 / 3)
+        lib.dsc_debug_set_gemm_stages(int(os.environ["DSC_GEMM_STAGES"]))
     _LIB = lib
     return lib
 

@@ -279,7 +279,11 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
+
 }  // namespace
+
+extern "C" void dsc_debug_set_gemm_stages(int stages) { g_gemm_stages = (stages == 2 || stages == 3) ? stages : 0; }
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                  int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
@@ -348,16 +352,29 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // 3 stages = 72 KiB -> two workgroups per CU.  A deeper ring (6 stages) was measured and changes nothing: a K tile
     // costs ~1000 cycles because a CU ingests only ~24 B/cycle from L2 (24 KiB per tile), not because of DMA latency -
     // the kernel is L2->LDS bandwidth bound at this tile size (43 FLOP per staged byte), which caps it near 25 % of the
     // MFMA peak; the dispatch in ops.linear therefore sends long-K shapes to hipBLASLt's larger macro-tiles.
-    const size_t lds = (size_t)3 * kStage * sizeof(half_t);          // the fp32 epilogue stage (34 KiB) reuses it
     const dim3 grid(mb * nb), block(T);
-    if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3>), grid, block, lds, st, p);
-    else DSC_LAUNCH((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
+    // Two stages (48 KiB: three workgroups per CU instead of two) for grids of many workgroups per CU: with K = 320 / 640 the
+    // K loop is a third of a workgroup's time (prologue DMA chain, LayerNorm / GEGLU epilogue), and a third co-resident
+    // workgroup overlaps those parts (tools/mb_gemm.py)
+    // measured: >= 300 workgroups -> two stages win (GEGLU N=2560 K=320 33.7 -> 30.9 us, N=5120 K=640 25.4 -> 22.6,
+    // M=512 N=10240 K=1280 26.5 -> 22.2); fewer workgroups with a long K loop want the deeper ring (N=640 K=2560 21.3 vs 27.0)
+    const int stages = g_gemm_stages ? g_gemm_stages : (mb * nb >= 300 ? 2 : 3);
+    const size_t lds = (size_t)stages * kStage * sizeof(half_t);     // the fp32 epilogue stage (34 KiB) reuses it
+    if (stages == 2) {
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 2>), grid, block, lds, st, p);
+    } else {
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
+    }
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 }  // namespace

@@ -444,7 +444,9 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
     if can and residual is not None:
         r2 = residual.reshape(M, N)
         can = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
-    ok = can and M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K
+    # GEGLU: the fused epilogue beats library GEMM + separate GEGLU launch at every row count of the UNet (tools/mb_gemm.py:
+    # M=512 N=10240 K=1280 22.2 vs 23.2 + the launch; M=128 12.5 vs 14.9)
+    ok = can and ((M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K) or (geglu and K <= 1280))
     if not ok:
         if ((USE_LT_RESIDUAL if residual is not None else USE_LT_ALL) and x.dtype == torch.float16 and K % 8 == 0
                 and N % 8 == 0 and M >= 8 and not (geglu and residual is not None)):
