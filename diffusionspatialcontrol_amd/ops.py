@@ -330,10 +330,26 @@ DSC_GEMM_MAX_K = 640       # kernels for >= 1024 token rows and K <= 640; hipBLA
 USE_LN_FOLD = os.environ.get("DSC_LN_FOLD", "1") != "0"   # BasicTransformerBlock: LayerNorms folded into the GEMMs (dsc_linear_ln_f16)
 
 
+DSC_GEMM_MID_ROWS = 512 if os.environ.get("DSC_GEMM_MID", "1") != "0" else 1 << 30    # 512 <= rows < 1024 (the 16x16 level at batch 1): the kernel up to K = 1280 - a wash per GEMM against the
+DSC_GEMM_MID_K = 1280      # library (QKV 14.0 vs 15.4 us, C->C 11.8 vs 11.1), but it lets the block's three LayerNorms fold into
+#                            its GEMMs (three add+LayerNorm launches of 6.5 us fewer) and K / V leave the QKV GEMM head-major
+
+
+def _gemm_rows_k_preferred(M, K, geglu=False):
+    """row / K window in which the hand-written GEMM is the faster (or launch-saving) choice; tools/mb_gemm.py"""
+    if M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K:
+        return True
+    if DSC_GEMM_MID_ROWS <= M < DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MID_K:
+        return True
+    # GEGLU: the fused epilogue beats library GEMM + separate GEGLU launch at every row count of the UNet (M=512 N=10240
+    # K=1280 22.2 vs 23.2 + the launch; M=128 12.5 vs 14.9)
+    return bool(geglu) and K <= 1280
+
+
 def linear_kernel_covers(M, N, K, dtype, geglu=False):
     """True when dsc_linear_f16 (the hand-written MFMA GEMM with fused epilogues) takes this shape"""
-    return (USE_DSC_GEMM and dtype == torch.float16 and K % 64 == 0 and N % 64 == 0 and M >= DSC_GEMM_MIN_ROWS
-            and K <= DSC_GEMM_MAX_K and (not geglu or (N // 2) % 32 == 0))
+    return (USE_DSC_GEMM and dtype == torch.float16 and K % 64 == 0 and N % 64 == 0 and _gemm_rows_k_preferred(M, K, geglu)
+            and (not geglu or (N // 2) % 32 == 0))
 
 
 def fold_layernorm(weight, bias, gamma, beta):
@@ -444,9 +460,7 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
     if can and residual is not None:
         r2 = residual.reshape(M, N)
         can = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
-    # GEGLU: the fused epilogue beats library GEMM + separate GEGLU launch at every row count of the UNet (tools/mb_gemm.py:
-    # M=512 N=10240 K=1280 22.2 vs 23.2 + the launch; M=128 12.5 vs 14.9)
-    ok = can and ((M >= DSC_GEMM_MIN_ROWS and K <= DSC_GEMM_MAX_K) or (geglu and K <= 1280))
+    ok = can and _gemm_rows_k_preferred(M, K, geglu)
     if not ok:
         if ((USE_LT_RESIDUAL if residual is not None else USE_LT_ALL) and x.dtype == torch.float16 and K % 8 == 0
                 and N % 8 == 0 and M >= 8 and not (geglu and residual is not None)):
