@@ -29,9 +29,10 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 64, BK = 64, T = 256;
-constexpr int kAHalves = BM * BK, kBHalves = BN * BK;       // one stage: A tile then B tile
-constexpr int kStage = kAHalves + kBHalves;                  // 12288 halves = 24 KiB
+constexpr int BN = 64, BK = 64, T = 256;
+constexpr int kBHalves = BN * BK;
+constexpr int a_halves(int bm) { return bm * BK; }           // one stage: A tile (BM tokens) then B tile
+constexpr int stage_halves(int bm) { return bm * BK + kBHalves; }   // BM = 128: 12288 halves = 24 KiB; BM = 64: 16 KiB
 constexpr int kEpiStride = BN + 4;                           // fp32 staging row stride: 68 dwords -> b128 writes conflict-free
 
 struct GemmParams {
@@ -81,13 +82,20 @@ __device__ __forceinline__ void row_stats(const GemmParams& p, long long m, floa
 }
 
 // GEGLU: the workgroup's 64 weight rows are 32 "hidden" rows n0h.. and the 32 matching "gate" rows N/2 + n0h..
-template <bool GEGLU, int STAGES>
+// BM = 128 token rows per workgroup, or 64 for GEMMs with few token rows (the 16x16 level: M = 512 gives 80 workgroups of
+// 128 rows on 256 CUs, each walking 20 K tiles alone; 64-row tiles double the workgroups and take 4 instead of 6 DMA pieces and
+// 4 instead of 8 MFMAs per wave and K tile)
+template <bool GEGLU, int STAGES, int BM>
 __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmParams p) {
+    static_assert(BM == 128 || (BM == 64 && !GEGLU), "tile heights");
+    constexpr int MT = BM / 64;                              // 32-row fragments per wave
+    constexpr int kAHalves = a_halves(BM), kStage = stage_halves(BM);
+    constexpr int kPieces = BM / 32 + 2;                     // DMA instructions per wave and K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* lds = reinterpret_cast<half_t*>(smem);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): 64 x 32 per wave
+    const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): (BM/2) x 32 per wave
     const int nb = GEGLU ? p.N / 64 : p.N / BN;              // column blocks (GEGLU: 32 output columns per block)
     const int bid = blockIdx.x;
     const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel (L2)
@@ -116,9 +124,11 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
         }
     };
 
-    f16x_t acc[2];
+    f16x_t acc[MT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
     const int nk = p.K / BK;
 #pragma unroll
@@ -148,12 +158,12 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
     }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % STAGES;
-        // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (6 DMA instructions each) are outstanding
+        // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (kPieces DMA instructions each) are outstanding
         const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (younger >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (younger == 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * kPieces) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kPieces) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kPieces) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPieces) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // raw: publishes tile kt, proves tile kt-1's reads are done
         if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
@@ -162,18 +172,20 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const h8_t wf = lds_frag(b, wn * 32 + r, 2 * ks + hh);                    // W[n][16 ks + 8 hh ..]
-            const h8_t x0 = lds_frag(a, wm * 64 + r, 2 * ks + hh);                    // X[m][...]
-            const h8_t x1 = lds_frag(a, wm * 64 + 32 + r, 2 * ks + hh);
-            acc[0] = mfma_32x32x16(wf, x0, acc[0]);
-            acc[1] = mfma_32x32x16(wf, x1, acc[1]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8_t xf = lds_frag(a, wm * (BM / 2) + mt * 32 + r, 2 * ks + hh);   // X[m][...]
+                acc[mt] = mfma_32x32x16(wf, xf, acc[mt]);
+            }
         }
     }
     // residual rows of this thread's four output chunks: issued before the staging pass so that their latency (HBM /
     // Infinity Cache: the residual stream was written by an earlier kernel) hides under it
-    h8_t rpre[4];
+    constexpr int NCH = BM / 32;                             // output chunks per thread (plain epilogue): 4 or 2
+    h8_t rpre[NCH];
     if (!GEGLU) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
             rpre[c] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
             if (p.res && m0 + row < p.M) rpre[c] = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
@@ -184,11 +196,11 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
     // ---- epilogue stage: stage[m][n] fp32; acc[mt] element i <-> n = wn*32 + (i&3) + 8(i>>2) + 4hh, m = wm*64 + mt*32 + r
     float* stage = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f4x_t v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-            *reinterpret_cast<f4x_t*>(stage + (wm * 64 + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = v;
+            *reinterpret_cast<f4x_t*>(stage + (wm * (BM / 2) + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = v;
         }
     float* rowst = stage + BM * kEpiStride;                  // [BM][2] (mu, rstd) of the folded LayerNorm, behind the stage
     if (p.ln_in && threadIdx.x < BM) { rowst[2 * threadIdx.x] = ln_mu; rowst[2 * threadIdx.x + 1] = ln_rs; }
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             }
         }
     } else {
-        // output tile 128 x 64: 8 chunks per row -> 1024 chunks, 4 per thread; a row's 8 chunks = one 128-B segment
+        // output tile BM x 64: 8 chunks per row -> 1024 (512) chunks, 4 (2) per thread; a row's 8 chunks = one 128-B segment
         const bool scat = p.kv != nullptr && n0 >= p.kv_C;       // workgroup-uniform (C is a multiple of the 64-column block)
         long long kv_col = 0;
         int kv_b0 = 0, kv_l0 = 0;
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
             kv_l0 = m0 - kv_b0 * p.kv_L;
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
             const bool live = m0 + row < p.M;                    // a row's 8 chunks sit in 8 consecutive lanes
             float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 1.f;
@@ -280,10 +292,16 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
+int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
 
 }  // namespace
 
-extern "C" void dsc_debug_set_gemm_stages(int stages) { g_gemm_stages = (stages == 2 || stages == 3) ? stages : 0; }
+extern "C" void dsc_debug_set_gemm_stages(int stages) {
+    // stages % 10: ring depth (2, 3; else default); stages / 10: tile height (64, 128; else default) - e.g. 640 + 3
+    const int bm = stages / 10, st = stages % 10;
+    g_gemm_stages = (st == 2 || st == 3) ? st : 0;
+    g_gemm_bm = (bm == 64 || bm == 128) ? bm : 0;
+}
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                  int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
@@ -345,17 +363,24 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
         p.kv = static_cast<half_t*>(kv_out);
         p.kv_C = N / 3; p.kv_H = heads; p.kv_d = N / 3 / heads; p.kv_L = seq_len; p.kv_B = (int)(M / seq_len);
     }
-    const int mb = (int)((M + BM - 1) / BM);
-    const int nb = geglu ? N / 64 : N / BN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64>)};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    // Tile height: 64 token rows when 128-row tiles would leave the chip half empty (fewer than 192 workgroups - the 16x16
+    // level's C->C GEMMs: M = 512, N = 1280 -> 80 workgroups walking 20 K tiles each) and the rows allow it; GEGLU keeps 128.
+    const int nb = geglu ? N / 64 : N / BN;
+    int bm = 128;
+    // (measured, tools/mb_gemm.py: M=512 N=1280 K=1280 11.8 -> 8.1 us, M=8192 N=320 K=320 9.1 -> 7.5, M=8192 N=320 K=1280 24.4 ->
+    // 20.7; at 480+ workgroups of 128 rows the taller tile wins: M=2048 N=1920 K=640 12.3 vs 13.5)
+    if (!geglu && (long long)((M + 127) / 128) * nb <= 320 && g_gemm_bm != 128) bm = 64;
+    if (g_gemm_bm == 64 && !geglu) bm = 64;
+    const int mb = (int)((M + bm - 1) / bm);
     // 3 stages = 72 KiB -> two workgroups per CU.  A deeper ring (6 stages) was measured and changes nothing: a K tile
     // costs ~1000 cycles because a CU ingests only ~24 B/cycle from L2 (24 KiB per tile), not because of DMA latency -
     // the kernel is L2->LDS bandwidth bound at this tile size (43 FLOP per staged byte), which caps it near 25 % of the
@@ -366,14 +391,25 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // workgroup overlaps those parts (tools/mb_gemm.py)
     // measured: >= 300 workgroups -> two stages win (GEGLU N=2560 K=320 33.7 -> 30.9 us, N=5120 K=640 25.4 -> 22.6,
     // M=512 N=10240 K=1280 26.5 -> 22.2); fewer workgroups with a long K loop want the deeper ring (N=640 K=2560 21.3 vs 27.0)
-    const int stages = g_gemm_stages ? g_gemm_stages : (mb * nb >= 300 ? 2 : 3);
-    const size_t lds = (size_t)stages * kStage * sizeof(half_t);     // the fp32 epilogue stage (34 KiB) reuses it
-    if (stages == 2) {
-        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2>), grid, block, lds, st, p);
-        else DSC_LAUNCH((gemm_tn_f16<false, 2>), grid, block, lds, st, p);
+    // ... and only while the K loop is short: K = 2560 / 5120 want the deeper ring whatever the grid (23.9 vs 22.6, 38.9 vs 27.9)
+    // In the STEP (cold weights: tools/step_breakdown.py on a kernel trace, gemm_tn per step) - 128-row tiles + 3 stages
+    // everywhere 1.65 ms, + this two-stage rule 1.59, 64-row tiles for the small grids with 3 stages 1.53, 64-row tiles WITH two
+    // stages 1.68: the short ring loses its prefetch depth exactly where every weight tile comes from HBM, which the
+    // back-to-back micro-benchmark (warm weights) ranks the other way round.  So: two stages only for the 128-row many-workgroup grids.
+    const int stages = g_gemm_stages ? g_gemm_stages : ((K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3);
+    // the fp32 epilogue stage (bm x 68 floats + the row statistics) reuses the ring
+    size_t lds = (size_t)stages * stage_halves(bm) * sizeof(half_t);
+    const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float);
+    if (lds < epi) lds = epi;
+    if (bm == 64) {
+        if (stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 64>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 3, 64>), grid, block, lds, st, p);
+    } else if (stages == 2) {
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2, 128>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 2, 128>), grid, block, lds, st, p);
     } else {
-        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3>), grid, block, lds, st, p);
-        else DSC_LAUNCH((gemm_tn_f16<false, 3>), grid, block, lds, st, p);
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3, 128>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 3, 128>), grid, block, lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -297,7 +297,8 @@ int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void
  * row segments 3C elements apart).  Same LayerNorm-folding arguments as dsc_linear_ln_f16 (ln_in NULL = plain GEMM).
  * Needs C % 64 == 0, (C / heads) % 8 == 0, K % 64 == 0, M % seq_len == 0.
  */
-/* diagnostics: force the K-tile ring depth of dsc_linear_f16 / _ln_f16 / _qkv_f16 (2 or 3 stages; 0 = the default) */
+/* diagnostics: force the K-tile ring depth of dsc_linear_f16 / _ln_f16 / _qkv_f16 (v % 10: 2 or 3 stages, else the default)
+ * and its tile height (v / 10: 64 or 128 token rows, else the default) - e.g. 643 = 64-row tiles, 3 stages; 0 = defaults */
 void dsc_debug_set_gemm_stages(int stages);
 int dsc_linear_qkv_f16(const void* x, const void* w, const void* bias, void* q_out, void* kv_out,
                        int64_t M, int C, int K, int64_t ldx, int64_t ldq, int heads, int seq_len,
