@@ -113,6 +113,12 @@ def load_library():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    if os.environ.get("DSC_SA_VARIANT"):                       # A/B switch: force one tiling of the flash self-attention kernel
+        lib.dsc_debug_set_self_attn_variant(int(os.environ["DSC_SA_VARIANT"]))
+    if os.environ.get("DSC_CONV_RING"):                        # A/B switch: weight-tile ring depth of the 3x3 convolution (3 / 9)
+        lib.dsc_debug_set_conv_ring(int(os.environ["DSC_CONV_RING"]))
+    if os.environ.get("DSC_GN_MODE"):                          # A/B switch: GroupNorm kernel selection (dsc_debug_set_gn_mode)
+        lib.dsc_debug_set_gn_mode(int(os.environ["DSC_GN_MODE"]))
     if os.environ.get("DSC_GEMM_STAGES"):                      # A/B switch: K-tile ring depth of the hand-written GEMM (2 / 3)
         lib.dsc_debug_set_gemm_stages(int(os.environ["DSC_GEMM_STAGES"]))
     _LIB = lib
