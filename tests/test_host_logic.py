@@ -596,3 +596,24 @@ def test_ip_adapter_plus_and_full_projection_conversion():
         assert n2 == 257 and torch.allclose(p2(x), full(x), atol=1e-6)
     with pytest.raises(NotImplementedError):
         conv({"norm.weight": torch.zeros(4), "proj.0.weight": torch.zeros(4, 4), "proj.2.weight": torch.zeros(4, 4)})   # FaceID
+
+
+# ------------------------------------------------------------------ bench.py launcher logic (no GPU needed)
+def test_bench_refuses_a_gpus_world_size_mismatch_and_self_launches():
+    """`python bench.py --gpus N`: under a launcher a --gpus that differs from WORLD_SIZE is an error that names the right
+    command; without one the parent starts N ranks itself (here they fail for lack of a GPU: the parent must relay a
+    NON-ZERO status, not 0)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("on a GPU box the ranks would really run: the launcher is exercised there by `bench.py --gpus 2` itself")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (r.stderr + r.stdout)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0                          # both ranks exit with "bench.py needs an MI355X"
+    assert "needs an MI355X" in (r.stderr + r.stdout)
