@@ -52,12 +52,14 @@ struct GemmParams {
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
-template <int ROWS>
+// `iw` of `NISS` issuing waves takes pieces iw, iw + NISS, ...
+template <int ROWS, int NISS>
 __device__ __forceinline__ void dma_tile(const half_t* g, long long ld, int row0, int rows_valid, int k0, half_t* lds,
-                                         int wave, int lane) {
+                                         int iw, int lane) {
+    static_assert((ROWS / 8) % NISS == 0, "pieces must divide among the issuing waves");
 #pragma unroll
-    for (int pc = 0; pc < ROWS / 8 / 4; ++pc) {
-        const int piece = pc * 4 + wave;
+    for (int pc = 0; pc < ROWS / 8 / NISS; ++pc) {
+        const int piece = pc * NISS + iw;
         const int row = piece * 8 + (lane >> 3);
         const int grow = min(row0 + row, rows_valid - 1);
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
@@ -85,12 +87,18 @@ __device__ __forceinline__ void row_stats(const GemmParams& p, long long m, floa
 // BM = 128 token rows per workgroup, or 64 for GEMMs with few token rows (the 16x16 level: M = 512 gives 80 workgroups of
 // 128 rows on 256 CUs, each walking 20 K tiles alone; 64-row tiles double the workgroups and take 4 instead of 6 DMA pieces and
 // 4 instead of 8 MFMAs per wave and K tile)
-template <bool GEGLU, int STAGES, int BM>
-__global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmParams p) {
+//
+// NLOAD > 0: NLOAD extra waves do nothing but the tiles' LDS-DMA (an LDS-DMA instruction costs the issuing wave 100-200 cycles
+// of issue time - 6 per K tile beside 8 MFMAs of 32 cycles in the plain kernel); the four computing waves then only read LDS
+// and issue MFMAs between the per-tile barriers, which all waves join.
+template <bool GEGLU, int STAGES, int BM, int NLOAD>
+__global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))) void gemm_tn_f16(GemmParams p) {
     static_assert(BM == 128 || (BM == 64 && !GEGLU), "tile heights");
+    constexpr bool LOADER = NLOAD > 0;
+    constexpr int NISS = LOADER ? NLOAD : 4;                 // waves that issue DMA
     constexpr int MT = BM / 64;                              // 32-row fragments per wave
     constexpr int kAHalves = a_halves(BM), kStage = stage_halves(BM);
-    constexpr int kPieces = BM / 32 + 2;                     // DMA instructions per wave and K tile
+    constexpr int kPieces = (BM / 8 + 8) / NISS;             // DMA instructions per issuing wave and K tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* lds = reinterpret_cast<half_t*>(smem);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -103,15 +111,16 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
     const int n0 = GEGLU ? bn * 32 : bn * BN;
     const int Nh = p.N / 2;
 
+    const int iw = LOADER ? wave - 4 : wave;                 // index among the issuing waves
     auto issue = [&](int kt, int buf) {
         half_t* a = lds + buf * kStage;
-        dma_tile<BM>(p.x, p.ldx, m0, p.M, kt * BK, a, wave, lane);
+        dma_tile<BM, NISS>(p.x, p.ldx, m0, p.M, kt * BK, a, iw, lane);
         if (GEGLU) {
             // B tile rows 0..31 = w[n0 .. n0+32), rows 32..63 = w[Nh + n0 .. Nh + n0 + 32): two half-tiles of 4 pieces
             half_t* b = a + kAHalves;
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int piece = pc * 4 + wave;             // 8 pieces of 8 rows
+            for (int pc = 0; pc < 8 / NISS; ++pc) {
+                const int piece = pc * NISS + iw;            // 8 pieces of 8 rows
                 const int row = piece * 8 + (lane >> 3);
                 const int grow = (row < 32 ? n0 + row : Nh + n0 + row - 32);
                 const int chunk = (lane & 7) ^ ((row >> 1) & 7);
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
                                                  (__attribute__((address_space(3))) void*)(b + piece * 512), 16, 0, 0);
             }
         } else {
-            dma_tile<BN>(p.w, p.K, n0, p.N, kt * BK, a + kAHalves, wave, lane);
+            dma_tile<BN, NISS>(p.w, p.K, n0, p.N, kt * BK, a + kAHalves, iw, lane);
         }
     };
 
@@ -131,9 +140,36 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
     const int nk = p.K / BK;
+    // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (kPieces DMA instructions each) are outstanding
+    auto wait_tile = [&](int kt) {
+        const int younger = min(STAGES - 2, nk - 1 - kt);
+        if (younger >= 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * kPieces) : "memory");
+        else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * kPieces) : "memory");
+        else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * kPieces) : "memory");
+        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kPieces) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kPieces) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPieces) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if constexpr (LOADER) {
+        if (wave >= 4) {                                     // a loader wave: the ring's DMA and nothing else
 #pragma unroll
-    for (int st = 0; st < STAGES - 1; ++st)
-        if (st < nk) issue(st, st);
+            for (int st = 0; st < STAGES - 1; ++st)
+                if (st < nk) issue(st, st);
+            for (int kt = 0; kt < nk; ++kt) {
+                wait_tile(kt);
+                __builtin_amdgcn_s_barrier();                // publishes tile kt; every computing wave has left tile kt-1's stage
+                if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+            }
+            __syncthreads();                                 // the epilogue's two workgroup barriers
+            __syncthreads();
+            return;
+        }
+    } else {
+#pragma unroll
+        for (int st = 0; st < STAGES - 1; ++st)
+            if (st < nk) issue(st, st);
+    }
     // folded LayerNorm: thread t < 128 owns row m0 + t's (mean, 1/std); the partial-sum loads ride under the K loop
     float ln_mu = 0.f, ln_rs = 1.f;
     if (p.ln_in && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) row_stats(p, m0 + threadIdx.x, ln_mu, ln_rs);
@@ -158,15 +194,11 @@ __global__ __launch_bounds__(T, (STAGES <= 3 ? 2 : 1)) void gemm_tn_f16(GemmPara
     }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % STAGES;
-        // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (kPieces DMA instructions each) are outstanding
-        const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * kPieces) : "memory");
-        else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kPieces) : "memory");
-        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kPieces) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPieces) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!LOADER) wait_tile(kt);
+        else asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // raw: publishes tile kt, proves tile kt-1's reads are done
-        if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+        asm volatile("" ::: "memory");
+        if (!LOADER && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const half_t* a = lds + buf * kStage;
         const half_t* b = a + kAHalves;
 #pragma unroll
@@ -293,14 +325,16 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
 int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
+int g_gemm_loaders = 0;          // ... (stages / 10000): 4 = the kernels with four loader waves
 
 }  // namespace
 
 extern "C" void dsc_debug_set_gemm_stages(int stages) {
     // stages % 10: ring depth (2, 3; else default); stages / 10: tile height (64, 128; else default) - e.g. 640 + 3
-    const int bm = stages / 10, st = stages % 10;
-    g_gemm_stages = (st == 2 || st == 3) ? st : 0;
+    const int bm = (stages / 10) % 1000, st = stages % 10;
+    g_gemm_stages = (st == 2 || st == 3 || st == 5 || st == 8) ? st : 0;   // 5 / 8: 64-row tiles of small grids only
     g_gemm_bm = (bm == 64 || bm == 128) ? bm : 0;
+    g_gemm_loaders = stages / 10000 == 4 ? 4 : 0;
 }
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -366,9 +400,12 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64>)};
+        const void* fns[] = {reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128, 0>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64, 0>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128, 4>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128, 4>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 5, 64, 0>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 8, 64, 0>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -396,20 +433,31 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // everywhere 1.65 ms, + this two-stage rule 1.59, 64-row tiles for the small grids with 3 stages 1.53, 64-row tiles WITH two
     // stages 1.68: the short ring loses its prefetch depth exactly where every weight tile comes from HBM, which the
     // back-to-back micro-benchmark (warm weights) ranks the other way round.  So: two stages only for the 128-row many-workgroup grids.
-    const int stages = g_gemm_stages ? g_gemm_stages : ((K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3);
+    int stages = (K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3;
+    if (g_gemm_stages == 2 || g_gemm_stages == 3) stages = g_gemm_stages;
+    else if (g_gemm_stages > 3 && bm == 64 && mb * nb <= (g_gemm_stages == 5 ? 512 : 256) && K / BK >= g_gemm_stages) stages = g_gemm_stages;
     // the fp32 epilogue stage (bm x 68 floats + the row statistics) reuses the ring
     size_t lds = (size_t)stages * stage_halves(bm) * sizeof(half_t);
     const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float);
     if (lds < epi) lds = epi;
-    if (bm == 64) {
-        if (stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 64>), grid, block, lds, st, p);
-        else DSC_LAUNCH((gemm_tn_f16<false, 3, 64>), grid, block, lds, st, p);
+    if (g_gemm_loaders == 4) {                               // diagnostics / A-B: the loader-wave kernels (3 stages)
+        lds = (size_t)3 * stage_halves(bm) * sizeof(half_t);
+        if (lds < epi) lds = epi;
+        const dim3 block8(T + 256);
+        if (bm == 64) DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 4>), grid, block8, lds, st, p);
+        else if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3, 128, 4>), grid, block8, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 3, 128, 4>), grid, block8, lds, st, p);
+    } else if (bm == 64) {
+        if (stages == 8) DSC_LAUNCH((gemm_tn_f16<false, 8, 64, 0>), grid, block, lds, st, p);
+        else if (stages == 5) DSC_LAUNCH((gemm_tn_f16<false, 5, 64, 0>), grid, block, lds, st, p);
+        else if (stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 64, 0>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 0>), grid, block, lds, st, p);
     } else if (stages == 2) {
-        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2, 128>), grid, block, lds, st, p);
-        else DSC_LAUNCH((gemm_tn_f16<false, 2, 128>), grid, block, lds, st, p);
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2, 128, 0>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 2, 128, 0>), grid, block, lds, st, p);
     } else {
-        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3, 128>), grid, block, lds, st, p);
-        else DSC_LAUNCH((gemm_tn_f16<false, 3, 128>), grid, block, lds, st, p);
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3, 128, 0>), grid, block, lds, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 3, 128, 0>), grid, block, lds, st, p);
     }
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
