@@ -60,9 +60,9 @@ _SIGNATURES = {
     "dsc_groupnorm_nhwc_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "dsc_debug_set_gn_mode": (None, [ctypes.c_int]),
     "dsc_groupnorm_silu_nhwc": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64] + [ctypes.c_int] * 4 +
-                                [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+                                [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "dsc_groupnorm_silu_nhwc_cat": (ctypes.c_int, [_vp, _vp, ctypes.c_int] + [_vp] * 5 + [ctypes.c_int64] + [ctypes.c_int] * 4 +
-                                    [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+                                    [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "dsc_set_workspace_slot": (ctypes.c_int, [ctypes.c_int]),
     "dsc_linear_lt_stats": (None, [_vp]),
     "dsc_add_bias_residual": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
@@ -73,7 +73,7 @@ _SIGNATURES = {
     "dsc_conv3x3_supported": (ctypes.c_int, [ctypes.c_int] * 5),
     "dsc_conv3x3_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "dsc_conv3x3_nhwc_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 5 + [ctypes.c_int64] * 3 +
-                             [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp, ctypes.c_size_t, _vp]),
+                             [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "dsc_conv3x3_fewcin_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 6 + [_vp]),
     "dsc_linear_lt_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                           [ctypes.c_int, _vp]),

@@ -50,12 +50,10 @@ struct ConvParams {
     long long onpix;              // output pixels (npix, or npix / 4 with sub2)
     long long ldx, ldr, ldo;      // pixel strides (elements)
     int nc, splits, cps;          // 64-channel slices, split count, slices per split
-    unsigned* cells;              // split-K arrival counter per output tile (zero between launches) or NULL: conv3x3_reduce sums
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
     int mt, nt;                   // tiles along pixels / output channels
     long long npix;
     unsigned x_bytes, w_bytes;    // extents for the buffer descriptors
-    unsigned ws_bytes;            // ... of the split-K partials (only with cells)
     long long* stamps;            // diagnostics (dsc_debug_set_conv_stamps): 8 x int64 per workgroup, NULL in normal calls
 };
 
@@ -308,13 +306,12 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
     // under it (the skip tensor was written by an earlier kernel: Infinity Cache / HBM)
     h8_t rpre[4];
     h8_t bpre = {0, 0, 0, 0, 0, 0, 0, 0};                           // bias of this thread's chunk column (the same in all four passes)
-    const bool fused_out = p.splits == 1 || p.cells != nullptr;   // this kernel writes fp16 `out` (possibly only its last arriver)
-    if (p.bias && fused_out && !p.nchw && n0 + (int)(threadIdx.x & 7) * 8 + 8 <= p.Cout)
+    if (p.bias && p.splits == 1 && !p.nchw && n0 + (int)(threadIdx.x & 7) * 8 + 8 <= p.Cout)
         bpre = *reinterpret_cast<const h8_t*>(p.bias + n0 + (threadIdx.x & 7) * 8);
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
         rpre[cidx] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.res && fused_out && !p.nchw) {
+        if (p.res && p.splits == 1 && !p.nchw) {
             const int idx = threadIdx.x + cidx * T, m = idx >> 3, ch = idx & 7;
             const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
             const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
@@ -351,16 +348,9 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
         }
         const float* sp_ = stage + m * kEpiStride + ch * 8;
         if (p.splits > 1) {
-            const long long e = ((long long)sp * p.onpix + gp) * p.Cout + n0 + ch * 8;
-            if (p.cells) {                                           // read by another workgroup of THIS launch: device-scope stores
-                const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, p.ws_bytes, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u4x_t*>(sp_), wsr, (unsigned)(e * 4), 0, kSc1);
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u4x_t*>(sp_ + 4), wsr, (unsigned)(e * 4) + 16, 0, kSc1);
-            } else {
-                float* dst = p.ws + e;
-                *reinterpret_cast<f4x_t*>(dst) = *reinterpret_cast<const f4x_t*>(sp_);
-                *reinterpret_cast<f4x_t*>(dst + 4) = *reinterpret_cast<const f4x_t*>(sp_ + 4);
-            }
+            float* dst = p.ws + ((long long)sp * p.onpix + gp) * p.Cout + n0 + ch * 8;
+            *reinterpret_cast<f4x_t*>(dst) = *reinterpret_cast<const f4x_t*>(sp_);
+            *reinterpret_cast<f4x_t*>(dst + 4) = *reinterpret_cast<const f4x_t*>(sp_ + 4);
         } else {
             const int c0 = n0 + ch * 8;
             if (c0 >= p.Cout) continue;                              // channel padding of a ragged last tile
@@ -384,54 +374,6 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
                         else p.out[gp * p.ldo + c] = (half_t)v;
                     }
                 }
-            }
-        }
-    }
-    if (p.splits > 1 && p.cells) {
-        // split-K without a second launch: the workgroup that arrives LAST at this tile's counter adds the partial tiles
-        // of all splits in split order (its own included, read back: the sum conv3x3_reduce forms, bit for bit), adds bias
-        // and residual and writes the fp16 tile; it leaves the counter at zero for the next launch.  Nobody waits.
-        // The partial tiles and the counter move with device-scope accesses (dsc_common.h): no cache-wide fence.
-        __shared__ int last_s;
-        dev_wait();                                                  // this wave's partial-tile stores are performed
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned* cell = p.cells + (bn * p.mt + bm);
-            const unsigned ticket = dev_add_u32(cell, 1u);
-            const int last = ticket == (unsigned)p.splits - 1;
-            if (last) dev_store_u32(cell, 0u);
-            last_s = last;
-        }
-        __syncthreads();
-        if (last_s) {
-            const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, p.ws_bytes, 0x00020000);
-#pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                const int idx = threadIdx.x + cidx * T, m = idx >> 3, ch = idx & 7;
-                const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
-                const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
-                if (b < 0) continue;
-                const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
-                long long gp = ((long long)b * p.H + yy) * p.W + xx;
-                if (p.sub2) {
-                    if (p.sub2 == 1 ? ((yy | xx) & 1) != 0 : (yy & xx & 1) == 0) continue;
-                    gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1);
-                }
-                unsigned off = (unsigned)((gp * p.Cout + n0 + ch * 8) * 4);
-                const unsigned pitch = (unsigned)(p.onpix * p.Cout * 4);
-                float acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int k = 0; k < p.splits; ++k) {
-                    const u4x_t ua = __builtin_amdgcn_raw_buffer_load_b128(wsr, off, 0, kSc1);
-                    const u4x_t ub = __builtin_amdgcn_raw_buffer_load_b128(wsr, off + 16, 0, kSc1);
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) { acc8[jj] += __uint_as_float(ua[jj]); acc8[4 + jj] += __uint_as_float(ub[jj]); }
-                    off += pitch;
-                }
-                const h8_t bv = bpre, rv = rpre[cidx];
-                h8_t o;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) o[jj] = (half_t)(acc8[jj] + (float)bv[jj] + (float)rv[jj]);
-                *reinterpret_cast<h8_t*>(p.out + gp * p.ldo + n0 + ch * 8) = o;
             }
         }
     }
@@ -471,8 +413,6 @@ __global__ __launch_bounds__(256) void conv3x3_reduce(ConvParams p) {
 
 long long* g_conv_stamps = nullptr;
 int g_conv_ring = 0;          // diagnostics (dsc_debug_set_conv_ring): 0 = from the grid size, 3 or 9 = forced
-int g_conv_fused_sum = 1;     // ... (dsc_debug_set_conv_ring(100 + v)): 0 = split-K always through the conv3x3_reduce launch
-constexpr int kGnCells = 128; // arrival cells the GroupNorm kernels use (2 per image, <= 64 images)
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -525,10 +465,7 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
-extern "C" void dsc_debug_set_conv_ring(int stages) {
-    if (stages >= 100) g_conv_fused_sum = stages - 100;
-    else g_conv_ring = stages;
-}
+extern "C" void dsc_debug_set_conv_ring(int stages) { g_conv_ring = stages; }
 
 extern "C" int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
     ConvParams p{};
@@ -546,7 +483,7 @@ extern "C" size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int 
 extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                     int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
                                     int resample, int out_nchw, int splits, int dtype, void* workspace,
-                                    size_t workspace_bytes, void* arrival_cells, size_t arrival_cells_bytes, void* stream) {
+                                    size_t workspace_bytes, void* stream) {
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
     if (ldx < Cin || (!out_nchw && ldo < Cout) || (residual && ldr < Cout)) return DSC_ERR_BAD_ARG;
@@ -577,14 +514,6 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
         const size_t need = (size_t)p.splits * p.onpix * Cout * sizeof(float);
         if (!workspace || workspace_bytes < need || !al16(workspace)) return DSC_ERR_WORKSPACE;
     }
-    // arrival cells [kGnCells ..): one per output tile; the first kGnCells belong to the GroupNorm kernels
-    p.cells = nullptr;
-    if (p.splits > 1 && arrival_cells && !(reinterpret_cast<uintptr_t>(arrival_cells) & 3) && !out_nchw && g_conv_fused_sum &&
-        arrival_cells_bytes >= (size_t)(kGnCells + p.mt * p.nt) * sizeof(unsigned) &&
-        (size_t)p.splits * p.onpix * Cout * sizeof(float) < ((size_t)1 << 31)) {
-        p.cells = static_cast<unsigned*>(arrival_cells) + kGnCells;
-        p.ws_bytes = (unsigned)((size_t)p.splits * p.onpix * Cout * sizeof(float));
-    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
@@ -607,7 +536,7 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
         else DSC_LAUNCH((conv3x3_kernel<8, 3>), grid, block, (size_t)lds_bytes(3), st, p);
     }
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
-    if (p.splits > 1 && !p.cells) {
+    if (p.splits > 1) {
         const long long n = p.onpix * (Cout / 8);
         DSC_LAUNCH(conv3x3_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;

@@ -10,7 +10,6 @@ typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 typedef float f16x_t __attribute__((ext_vector_type(16)));
 typedef float f4x_t __attribute__((ext_vector_type(4)));
 typedef float f2x_t __attribute__((ext_vector_type(2)));
-typedef unsigned u4x_t __attribute__((ext_vector_type(4)));
 
 #define DSC_WAVE 64
 
@@ -59,27 +58,3 @@ __device__ __forceinline__ float wave_sum_f32(float x) {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
 }
-
-// ---- device-scope traffic between the workgroups of ONE running kernel (arrival cells, include/dsc_hip.h) ------------------
-// Each XCD has its own L2.  A fence at device scope (__threadfence, acquire / release atomics) makes the wave write back and
-// invalidate that whole L2 - measured here: +60..80 us on a kernel whose workgroups each fence once.  These accesses carry the
-// scope themselves instead (the sc1 bit: served at the memory side, which all XCDs share), so nothing cache-wide runs; the
-// ordering comes from waiting for the wave's own accesses (dev_wait) before the workgroup barrier / the arrival.
-constexpr int kSc1 = 16;      // the same scope as a buffer-instruction cache policy (raw_buffer_load / store aux operand)
-__device__ __forceinline__ void dev_store_f64(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double dev_load_f64(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void dev_store_f32(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float dev_load_f32(const float* p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ unsigned dev_load_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void dev_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned dev_add_u32(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// every memory access this wave has issued is complete (stores: performed at their scope)
-__device__ __forceinline__ void dev_wait() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }

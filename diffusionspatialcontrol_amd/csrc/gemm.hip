@@ -22,6 +22,8 @@
 //     `s_waitcnt vmcnt(6*(STAGES-2))` + a RAW s_barrier publish tile t without draining the younger DMAs
 //     (__syncthreads() would wait vmcnt(0)); the refill of a buffer is issued right after the barrier that proves every
 //     wave finished reading it (one barrier per K tile);
+//   * optionally four more waves that do nothing but issue the ring's DMA (NLOAD; an LDS-DMA instruction holds its wave's
+//     issue port for 100-200 cycles, 6 per K tile beside 8 MFMAs of 32 cycles): the default for the 64-row tiles;
 //   * epilogue through LDS: accumulators (fp32) are transposed via an LDS stage so that bias / residual reads and the
 //     fp16 stores are full 128-byte row segments instead of 8-byte column-strided pieces; ONE fp16 rounding.
 #include "dsc_common.h"
@@ -143,9 +145,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (kPieces DMA instructions each) are outstanding
     auto wait_tile = [&](int kt) {
         const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (younger >= 6) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * kPieces) : "memory");
-        else if (younger == 5) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(5 * kPieces) : "memory");
-        else if (younger == 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * kPieces) : "memory");
+        if (younger >= 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * kPieces) : "memory");
         else if (younger == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kPieces) : "memory");
         else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kPieces) : "memory");
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPieces) : "memory");
@@ -325,16 +325,16 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
 int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
-int g_gemm_loaders = 0;          // ... (stages / 10000): 4 = the kernels with four loader waves
+int g_gemm_loaders = 0;          // ... (stages / 10000): 0 = default (loader waves for the 64-row tiles), 4 = for every tile, 9 = never
 
 }  // namespace
 
 extern "C" void dsc_debug_set_gemm_stages(int stages) {
     // stages % 10: ring depth (2, 3; else default); stages / 10: tile height (64, 128; else default) - e.g. 640 + 3
     const int bm = (stages / 10) % 1000, st = stages % 10;
-    g_gemm_stages = (st == 2 || st == 3 || st == 5 || st == 8) ? st : 0;   // 5 / 8: 64-row tiles of small grids only
+    g_gemm_stages = (st == 2 || st == 3) ? st : 0;
     g_gemm_bm = (bm == 64 || bm == 128) ? bm : 0;
-    g_gemm_loaders = stages / 10000 == 4 ? 4 : 0;
+    g_gemm_loaders = (stages / 10000 == 4 || stages / 10000 == 9) ? stages / 10000 : 0;
 }
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -404,8 +404,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
                              reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0>),
                              reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64, 0>),
                              reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128, 4>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128, 4>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 5, 64, 0>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 8, 64, 0>)};
+                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -433,14 +432,17 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // everywhere 1.65 ms, + this two-stage rule 1.59, 64-row tiles for the small grids with 3 stages 1.53, 64-row tiles WITH two
     // stages 1.68: the short ring loses its prefetch depth exactly where every weight tile comes from HBM, which the
     // back-to-back micro-benchmark (warm weights) ranks the other way round.  So: two stages only for the 128-row many-workgroup grids.
-    int stages = (K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3;
-    if (g_gemm_stages == 2 || g_gemm_stages == 3) stages = g_gemm_stages;
-    else if (g_gemm_stages > 3 && bm == 64 && mb * nb <= (g_gemm_stages == 5 ? 512 : 256) && K / BK >= g_gemm_stages) stages = g_gemm_stages;
+    // (5- and 8-stage rings for the 64-row tiles of the small grids, in the step: M=512 N=1280 K=1280 10.8 -> 11.0 / 11.2 us,
+    // M=2048 N=640 K=640 9.0 -> 9.9: the K loop is bound by what one CU ingests from L2, not by DMA latency, cold weights or not)
+    const int stages = g_gemm_stages ? g_gemm_stages : ((K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3);
     // the fp32 epilogue stage (bm x 68 floats + the row statistics) reuses the ring
     size_t lds = (size_t)stages * stage_halves(bm) * sizeof(half_t);
     const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float);
     if (lds < epi) lds = epi;
-    if (g_gemm_loaders == 4) {                               // diagnostics / A-B: the loader-wave kernels (3 stages)
+    // Four DMA-only loader waves beside the four computing ones: in the step 1-3 % on the 64-row-tile GEMMs (10.7 -> 10.6,
+    // 9.6 -> 9.3, 8.9 -> 8.7 us; 5-20 % back to back with warm weights, tools/chk_gemm_loader.py), while the 128-row tiles
+    // of the big grids keep the two-stage ring and three workgroups per CU (with loaders and three stages: GEGLU 29.7 -> 31.9 us)
+    if (g_gemm_loaders == 4 || (g_gemm_loaders == 0 && bm == 64 && stages == 3)) {
         lds = (size_t)3 * stage_halves(bm) * sizeof(half_t);
         if (lds < epi) lds = epi;
         const dim3 block8(T + 256);
@@ -448,9 +450,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
         else if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 3, 128, 4>), grid, block8, lds, st, p);
         else DSC_LAUNCH((gemm_tn_f16<false, 3, 128, 4>), grid, block8, lds, st, p);
     } else if (bm == 64) {
-        if (stages == 8) DSC_LAUNCH((gemm_tn_f16<false, 8, 64, 0>), grid, block, lds, st, p);
-        else if (stages == 5) DSC_LAUNCH((gemm_tn_f16<false, 5, 64, 0>), grid, block, lds, st, p);
-        else if (stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 64, 0>), grid, block, lds, st, p);
+        if (stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 64, 0>), grid, block, lds, st, p);
         else DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 0>), grid, block, lds, st, p);
     } else if (stages == 2) {
         if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2, 128, 0>), grid, block, lds, st, p);

@@ -13,15 +13,6 @@
 //                               its own 40 KB of activations)
 //   launch 3 gn_nhwc_apply    : folds mean/rstd/gamma/beta(/add) into one scale+shift per channel, streams its rows:
 //                               y = silu(x*sc + sh)
-//   ONE launch gn_nhwc_coop   : with caller-provided arrival cells (zeroed once, see dsc_hip.h) and a grid of at most
-//                               256 workgroups: every workgroup keeps its rows in registers, writes its partials and
-//                               arrives at a per-image counter; the LAST arriver adds the partials (the finalize pass,
-//                               same fixed order) and opens the image's barrier; the others wait for it, then everybody
-//                               normalises its registers.  One read of x instead of two, one launch instead of three
-//                               (a launch costs ~4.5 us of fixed time on this device whatever it moves).  A waiting
-//                               workgroup that is not released within 20 ms (its peers not resident: more spinning
-//                               kernels in flight than the chip holds) computes the image's statistics itself from x and
-//                               goes on - slow, the same numbers up to the fp64 summation order, never a hang.
 // HBM-bound: algorithmic bytes = 2 * B*hw*C*2 (read + write); the second read hits L2 / Infinity Cache.
 #include "dsc_common.h"
 #include "dsc_hip.h"
@@ -42,8 +33,6 @@ struct GnN {
     // concatenation mode (dsc_groupnorm_silu_nhwc_cat): the input is the channel concatenation [x | x2] (C1 channels from
     // x, C - C1 from x2) that was never materialised; the pass that reads the sources also writes it to `cat`
     const half_t* x2; half_t* cat; int C1;
-    unsigned* cells;             // gn_nhwc_coop: [B][2] = (arrivals, generation) per image
-    long long spin_ticks;        // ... wait bound in 100 MHz ticks (0: do not wait at all - the fallback, for the tests)
 };
 
 // element (b, pix, channel c .. c+7) of the input; in concatenation mode read from the source that holds c and copied to cat
@@ -202,229 +191,6 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     }
     for (int row = r0 + slice + kPre * p.k; row < r1; row += p.k)
         emit(row, *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C));
-}
-
-// ---- the one-launch form -------------------------------------------------------------------------------------------
-// per-thread channel sums over rows r0 + slice, r0 + slice + k, ... < r1 -> LDS -> per channel -> per group (fp64), the
-// order gn_nhwc_stats uses; threads < G return with their group's (sum, sumsq) in (a1, a2)
-__device__ __forceinline__ void group_sums(const GnN& p, char* smem, const float (&s)[8], const float (&q)[8], double& a1, double& a2) {
-    float* ssum = reinterpret_cast<float*>(smem);
-    float* ssq = ssum + p.k * p.C;
-    double* tot = reinterpret_cast<double*>(ssq + p.k * p.C);
-    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { ssum[slice * p.C + c8 * 8 + j] = s[j]; ssq[slice * p.C + c8 * 8 + j] = q[j]; }
-    __syncthreads();
-    if (p.k > 1) {
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
-            double c1 = 0.0, c2 = 0.0;
-            for (int sl = 0; sl < p.k; ++sl) { c1 += (double)ssum[sl * p.C + c]; c2 += (double)ssq[sl * p.C + c]; }
-            tot[2 * c] = c1; tot[2 * c + 1] = c2;
-        }
-        __syncthreads();
-    }
-    a1 = 0.0; a2 = 0.0;
-    if (threadIdx.x < p.G) {
-        const int g = threadIdx.x;
-        if (p.k > 1) for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += tot[2 * c]; a2 += tot[2 * c + 1]; }
-        else for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += (double)ssum[c]; a2 += (double)ssq[c]; }
-    }
-}
-
-template <int NV>
-__global__ __launch_bounds__(kMaxT) void gn_nhwc_coop(GnN p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float mean_s[64], rstd_s[64];
-    __shared__ double red[8 * 64 * 2];
-    __shared__ int role_s;                                     // 1 last arriver, 0 released by it, 2 gave up waiting
-    const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
-    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
-    const int r0 = chunk * p.rows, r1 = min(r0 + p.rows, p.HW);
-    float ad[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ad[j] = 0.f;
-    if (p.add) {
-        const h8_t a = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ad[j] = (float)a[j];
-    }
-    const half_t* base = p.x + (long long)b * p.HW * p.C + c8 * 8;
-    int rs = p.C;
-    half_t* cdst = nullptr;
-    if (p.x2) {
-        const int c2 = p.C - p.C1;
-        if (c8 * 8 < p.C1) { base = p.x + (long long)b * p.HW * p.C1 + c8 * 8; rs = p.C1; }
-        else { base = p.x2 + (long long)b * p.HW * c2 + (c8 * 8 - p.C1); rs = c2; }
-        cdst = p.cat + (long long)b * p.HW * p.C + c8 * 8;
-    }
-    // this workgroup's rows: read once, kept packed in registers for the normalisation
-    h8_t v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int row = r0 + slice + i * p.k;
-        v[i] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        if (row < r1) v[i] = *reinterpret_cast<const h8_t*>(base + (long long)row * rs);
-    }
-    float s[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int row = r0 + slice + i * p.k;
-        if (row < r1) {
-            if (cdst) *reinterpret_cast<h8_t*>(cdst + (long long)row * p.C) = v[i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[i][j] + ad[j]; s[j] += f; q[j] += f * f; }
-        }
-    }
-    double a1, a2;
-    group_sums(p, smem, s, q, a1, a2);
-    unsigned* cnt = p.cells + 2 * b;
-    unsigned* gen = cnt + 1;
-    // what crosses workgroups inside this launch (partials, statistics, the cells) moves with device-scope accesses
-    // (dsc_common.h): no cache-wide fence
-    if (threadIdx.x < p.G) {
-        double* dst = p.partials + (((long long)b * p.nchunk + chunk) * p.G + threadIdx.x) * 2;
-        dev_store_f64(dst, a1); dev_store_f64(dst + 1, a2);
-        dev_wait();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned gen0 = dev_load_u32(gen);               // read BEFORE this workgroup arrives: cannot have moved on yet
-        dev_wait();
-        const unsigned ticket = dev_add_u32(cnt, 1u);
-        int role = 1;
-        if (ticket != (unsigned)p.nchunk - 1) {
-            role = 2;
-            const long long t0 = wall_clock64();
-            do {
-                if (dev_load_u32(gen) != gen0) { role = 0; break; }
-                __builtin_amdgcn_s_sleep(8);
-            } while (wall_clock64() - t0 < p.spin_ticks);
-        }
-        role_s = role;
-    }
-    __syncthreads();
-    const int role = role_s;
-    if (role == 1) {
-        // the finalize pass: thread (g, part) adds chunks part, part + P, ... in order, then the P parts in order
-        const int P = min(8, (int)blockDim.x / p.G);
-        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
-        if (part < P) {
-            // (sum, sumsq) of a chunk = one 16-byte device-scope load; eight in flight per thread (a memory-side round
-            // trip each: issued one after the other they were most of this kernel's time)
-            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(p.partials + (long long)b * p.nchunk * p.G * 2, 0,
-                                                                                 (unsigned)(p.nchunk * p.G * 16), 0x00020000);
-            double t1 = 0.0, t2 = 0.0;
-            for (int i0 = part; i0 < p.nchunk; i0 += 8 * P) {
-                u4x_t w[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + u * P;
-                    w[u] = u4x_t{0, 0, 0, 0};
-                    if (i < p.nchunk) w[u] = __builtin_amdgcn_raw_buffer_load_b128(pr, (unsigned)((i * p.G + g) * 16), 0, kSc1);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {                    // zero words of a missing chunk add nothing
-                    t1 += __longlong_as_double((long long)(((unsigned long long)w[u][1] << 32) | w[u][0]));
-                    t2 += __longlong_as_double((long long)(((unsigned long long)w[u][3] << 32) | w[u][2]));
-                }
-            }
-            red[(part * 64 + g) * 2] = t1; red[(part * 64 + g) * 2 + 1] = t2;
-        }
-        __syncthreads();
-        if (threadIdx.x < p.G) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int w = 0; w < P; ++w) { t1 += red[(w * 64 + threadIdx.x) * 2]; t2 += red[(w * 64 + threadIdx.x) * 2 + 1]; }
-            const double n = (double)p.HW * p.cpg;
-            const double m = t1 / n;
-            double var = t2 / n - m * m;
-            var = var > 0.0 ? var : 0.0;
-            const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)p.eps));
-            mean_s[threadIdx.x] = mf; rstd_s[threadIdx.x] = rf;
-            dev_store_f32(p.stats + ((long long)b * p.G + threadIdx.x) * 2, mf);
-            dev_store_f32(p.stats + ((long long)b * p.G + threadIdx.x) * 2 + 1, rf);
-            dev_wait();
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            dev_store_u32(cnt, 0u);                            // ready for the next launch on these cells
-            dev_wait();
-            dev_add_u32(gen, 1u);                              // opens the barrier
-        }
-    } else if (role == 0) {
-        if (threadIdx.x < p.G) {
-            mean_s[threadIdx.x] = dev_load_f32(p.stats + ((long long)b * p.G + threadIdx.x) * 2);
-            rstd_s[threadIdx.x] = dev_load_f32(p.stats + ((long long)b * p.G + threadIdx.x) * 2 + 1);
-        }
-        __syncthreads();
-    } else {
-        // not released in time: the whole image's sums by this workgroup alone (x is in L2 / Infinity Cache by now)
-        float fs[8], fq[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { fs[j] = 0.f; fq[j] = 0.f; }
-        for (int row = slice; row < p.HW; row += p.k) {
-            const h8_t w = *reinterpret_cast<const h8_t*>(base + (long long)row * rs);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)w[j] + ad[j]; fs[j] += f; fq[j] += f * f; }
-        }
-        __syncthreads();
-        double t1, t2;
-        group_sums(p, smem, fs, fq, t1, t2);
-        if (threadIdx.x < p.G) {
-            const double n = (double)p.HW * p.cpg;
-            const double m = t1 / n;
-            double var = t2 / n - m * m;
-            var = var > 0.0 ? var : 0.0;
-            mean_s[threadIdx.x] = (float)m;
-            rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + (double)p.eps));
-        }
-        __syncthreads();
-    }
-    float sc[8], sh[8];
-    {
-        const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + c8 * 8);
-        const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + c8 * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int g = (c8 * 8 + j) / p.cpg;
-            sc[j] = (float)ga[j] * rstd_s[g];
-            sh[j] = (float)be[j] + (ad[j] - mean_s[g]) * sc[j];
-        }
-    }
-    half_t* yb = p.y + (long long)b * p.HW * p.C + c8 * 8;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int row = r0 + slice + i * p.k;
-        if (row < r1) {
-            h8_t o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = (float)v[i][j] * sc[j] + sh[j];
-                if (p.silu) f = silu_f(f);
-                o[j] = (half_t)f;
-            }
-            *reinterpret_cast<h8_t*>(yb + (long long)row * p.C) = o;
-        }
-    }
-}
-
-// chunking of the one-launch form: at most 256 workgroups in all (one per CU: two such kernels in flight on two streams,
-// and more, stay co-resident), at most NV rows per thread; false when the tensor is too large for that
-bool coop_plan(GnN& p, int* nv) {
-    if (p.B > 64) return false;
-    int target = 256 / p.B;
-    if (target < 1) return false;
-    int rows = (p.HW + target - 1) / target;
-    if (rows < p.arows) rows = p.arows;                       // never more chunks than the workspace's partials hold (anchunk)
-    const int per_thread = (rows + p.k - 1) / p.k;
-    if (per_thread > 16) return false;
-    *nv = per_thread <= 4 ? 4 : (per_thread <= 8 ? 8 : 16);
-    const int nchunk = (p.HW + rows - 1) / rows;
-    if (nchunk > p.anchunk) return false;
-    p.rows = rows;
-    p.nchunk = nchunk;
-    return true;
 }
 
 // Small images (the 8x8 / 16x16 UNet levels): ONE launch, one workgroup per (image, group).  The group's slab
@@ -649,8 +415,7 @@ bool plan(GnN& p) {
     return true;
 }
 
-int g_gn_mode = 0;   // diagnostics (dsc_debug_set_gn_mode): 0 auto, 2 never a single-launch kernel, 3 also the 1024-thread bundle kernel, 4 = 2 + separate finalize launch,
-                     // 5 = the one-launch form's waiters give up at once (exercises its fallback), 6 = never the one-launch form
+int g_gn_mode = 0;   // diagnostics (dsc_debug_set_gn_mode): 0 auto, 2 never a single-launch kernel, 3 also the 1024-thread bundle kernel, 4 = 2 + separate finalize launch
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -695,33 +460,31 @@ extern "C" size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int g
 namespace {
 int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, const void* gamma, const void* beta, const void* add,
                   int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
-                  void* workspace, size_t workspace_bytes, void* cells, size_t cells_bytes, void* stream);
+                  void* workspace, size_t workspace_bytes, void* stream);
 }
 
 extern "C" int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta, const void* add,
                                        int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
-                                       void* workspace, size_t workspace_bytes, void* arrival_cells, size_t arrival_cells_bytes,
-                                       void* stream) {
+                                       void* workspace, size_t workspace_bytes, void* stream) {
     return run_groupnorm(x, nullptr, 0, nullptr, y, gamma, beta, add, add_row_stride, B, C, hw, groups, eps, apply_silu, dtype,
-                         workspace, workspace_bytes, arrival_cells, arrival_cells_bytes, stream);
+                         workspace, workspace_bytes, stream);
 }
 
 extern "C" int dsc_groupnorm_silu_nhwc_cat(const void* x1, const void* x2, int C1, void* cat, void* y, const void* gamma,
                                            const void* beta, const void* add, int64_t add_row_stride, int B, int C, int hw,
                                            int groups, float eps, int apply_silu, int dtype, void* workspace,
-                                           size_t workspace_bytes, void* arrival_cells, size_t arrival_cells_bytes, void* stream) {
+                                           size_t workspace_bytes, void* stream) {
     if (!x2 || !cat || C1 <= 0 || C1 >= C) return DSC_ERR_BAD_ARG;
     if (C1 % 8 != 0 || !al16(x2) || !al16(cat) || cat == x1 || cat == x2 || cat == y) return DSC_ERR_UNSUPPORTED;
     return run_groupnorm(x1, x2, C1, cat, y, gamma, beta, add, add_row_stride, B, C, hw, groups, eps, apply_silu, dtype,
-                         workspace, workspace_bytes, arrival_cells, arrival_cells_bytes, stream);
+                         workspace, workspace_bytes, stream);
 }
 
 namespace {
 int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, const void* gamma, const void* beta, const void* add,
                   int64_t add_row_stride, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
-                  void* workspace, size_t workspace_bytes, void* cells, size_t cells_bytes, void* stream) {
+                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !y || !gamma || !beta || B <= 0 || C <= 0 || hw <= 0 || groups <= 0) return DSC_ERR_BAD_ARG;
-    if (cells && (reinterpret_cast<uintptr_t>(cells) & 3)) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
     GnN p{};
     p.B = B; p.C = C; p.HW = hw; p.G = groups;
@@ -757,26 +520,13 @@ int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, con
         }
     }
     const dim3 block(p.cv * p.k);
-    const size_t stats_lds = (size_t)2 * p.k * C * sizeof(float) + (size_t)2 * C * sizeof(double);
-    static bool attr_set = false;
-    if (stats_lds > 64 * 1024 && !attr_set) {
-        const void* fns[] = {reinterpret_cast<const void*>(&gn_nhwc_stats), reinterpret_cast<const void*>(&gn_nhwc_coop<4>),
-                             reinterpret_cast<const void*>(&gn_nhwc_coop<8>), reinterpret_cast<const void*>(&gn_nhwc_coop<16>)};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    int nv = 0;
-    if (cells && cells_bytes >= (size_t)2 * B * sizeof(unsigned) && g_gn_mode != 4 && g_gn_mode != 6 && coop_plan(p, &nv)) {
-        p.cells = static_cast<unsigned*>(cells);
-        p.spin_ticks = g_gn_mode == 5 ? 0 : 2000000;              // 20 ms of the 100 MHz wall clock
-        const dim3 grid(B * p.nchunk);
-        if (nv == 4) DSC_LAUNCH(gn_nhwc_coop<4>, grid, block, stats_lds, st, p);
-        else if (nv == 8) DSC_LAUNCH(gn_nhwc_coop<8>, grid, block, stats_lds, st, p);
-        else DSC_LAUNCH(gn_nhwc_coop<16>, grid, block, stats_lds, st, p);
-        return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
-    }
     if (g_gn_mode == 4) {                                        // diagnostics: the three-launch form
         p.rows = p.arows; p.nchunk = p.anchunk; p.inline_stats = 0;
+    }
+    const size_t stats_lds = (size_t)2 * p.k * C * sizeof(float) + (size_t)2 * C * sizeof(double);
+    if (stats_lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_nhwc_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     }
     DSC_LAUNCH(gn_nhwc_stats, dim3(B * p.nchunk), block, stats_lds, st, p);
     if (!p.inline_stats) DSC_LAUNCH(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);

@@ -1074,17 +1074,7 @@ class StableDiffusionPipeline:
 
         ukw = {} if ack is None else {"added_cond_kwargs": {"image_embeds": st["image_embeds"]}}
 
-        # arrival cells of this slot's step (ops.arrival_cells): allocated here, outside the capture, one block per slot -
-        # the steps of two slots replay concurrently on two streams
-        st["cells"] = ops.new_arrival_cells(dev)
-
         def step():
-            if not ops.USE_ARRIVAL_CELLS:
-                return step_body()
-            with ops.arrival_cells(st["cells"]):
-                return step_body()
-
-        def step_body():
             extra = dict(ukw)
             if st["cn"] is not None:                # ControlNet on the same scaled input and timestep as the UNet (:1134-1142)
                 cn = st["cn"]

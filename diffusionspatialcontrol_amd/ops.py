@@ -1,9 +1,7 @@
 """Thin torch-tensor wrappers over the C ABI (include/dsc_hip.h).  torch is plumbing here: device memory,
 the current HIP stream and strides; all arithmetic happens in libdsc_hip.so."""
-import contextlib
 import ctypes
 import os
-import threading
 
 import numpy as np
 import torch
@@ -37,36 +35,6 @@ def _workspace(device, nbytes):
     HIP-graph capture the allocation must belong to that graph's private pool, and a buffer remembered from an
     earlier (since destroyed) capture would alias live activations of the next one."""
     return torch.empty(max(nbytes, 16) // 8 + 1, dtype=torch.float64, device=device)
-
-
-ARRIVAL_CELLS_BYTES = 16384      # DSC_ARRIVAL_CELLS_BYTES (include/dsc_hip.h)
-USE_ARRIVAL_CELLS = os.environ.get("DSC_ARRIVAL_CELLS", "0") != "0"   # the captured UNet step opens an arrival_cells scope (measured slower: DESIGN.md)
-_arrival = threading.local()
-
-
-def new_arrival_cells(device):
-    """a zeroed block of arrival cells (include/dsc_hip.h, ARRIVAL CELLS).  Allocate it OUTSIDE any graph capture and keep
-    it alive as long as a graph captured under `arrival_cells(block)` may replay."""
-    return torch.zeros(ARRIVAL_CELLS_BYTES // 4, dtype=torch.int32, device=device)
-
-
-@contextlib.contextmanager
-def arrival_cells(block):
-    """every GroupNorm / split-K convolution issued by this thread inside the scope gets `block` as its arrival cells:
-    the one-launch forms (the last workgroup to arrive does the finalize / the split sum).  The calls of one scope must be
-    stream-ordered among themselves (one stream, or one captured graph), and two scopes that may run concurrently need a
-    block each - the step builder keeps one per generation slot."""
-    prev = getattr(_arrival, "block", None)
-    _arrival.block = block
-    try:
-        yield
-    finally:
-        _arrival.block = prev
-
-
-def _cells():
-    t = getattr(_arrival, "block", None)
-    return (_p(t), t.numel() * 4) if t is not None else (None, 0)
 
 
 def _blhd_strides(t, layout):
@@ -313,7 +281,7 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
         add_stride = add.stride(0)
     ws = _workspace(x.device, lib.dsc_groupnorm_nhwc_workspace_bytes(B, C, hw, groups))
     rc = lib.dsc_groupnorm_silu_nhwc(_p(x), _p(y), _p(weight), _p(bias), _p(add), add_stride, B, C, hw, groups, float(eps),
-                                     1 if act else 0, 0, _p(ws), ws.numel() * 8, *_cells(), _stream_ptr(x))
+                                     1 if act else 0, 0, _p(ws), ws.numel() * 8, _stream_ptr(x))
     _lib.check(rc, "dsc_groupnorm_silu_nhwc")
     return y
 
@@ -348,7 +316,7 @@ def groupnorm_silu_nhwc_cat(x1, x2, groups, weight, bias, eps, act, add=None):
         add_stride = add.stride(0)
     ws = _workspace(x1.device, lib.dsc_groupnorm_nhwc_workspace_bytes(B, C, h * w, groups))
     rc = lib.dsc_groupnorm_silu_nhwc_cat(_p(x1), _p(x2), C1, _p(cat), _p(y), _p(weight), _p(bias), _p(add), add_stride, B, C,
-                                         h * w, groups, float(eps), 1 if act else 0, 0, _p(ws), ws.numel() * 8, *_cells(),
+                                         h * w, groups, float(eps), 1 if act else 0, 0, _p(ws), ws.numel() * 8,
                                          _stream_ptr(x1))
     _lib.check(rc, "dsc_groupnorm_silu_nhwc_cat")
     return y, cat
@@ -578,7 +546,7 @@ def conv3x3(x, weight, bias=None, residual=None, splits=0, upsample=False, out_n
     ws = _workspace(x.device, nbytes) if nbytes else None
     rc = lib.dsc_conv3x3_nhwc_f16(_p(x), _p(weight), _p(bias), _p(residual), _p(out), B, H, W, Cin, Cout, Cin, ldr, Cout,
                                   3 if stride2_pad_br else (2 if stride2 else (1 if upsample else 0)), 1 if out_nchw else 0, splits, 0, _p(ws),
-                                  ws.numel() * 8 if ws is not None else 0, *_cells(), _stream_ptr(x))
+                                  ws.numel() * 8 if ws is not None else 0, _stream_ptr(x))
     _lib.check(rc, "dsc_conv3x3_nhwc_f16")
     return out
 

@@ -205,25 +205,12 @@ int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, const void* be
  */
 size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int groups);
 /* diagnostics: 0 = choose the kernel from the shape, 2 = always stats / finalize / apply, 3 = also allow the
- * 1024-thread single-launch kernel (measured slower than three launches; kept for tools/mb_gn.py), 4 = 2 with the
- * separate finalize launch, 5 = the one-launch form's waiting workgroups give up at once (exercises its fallback),
- * 6 = never the one-launch form */
+ * 1024-thread single-launch kernel (measured slower than three launches; kept for tools/mb_gn.py) */
 void dsc_debug_set_gn_mode(int mode);
-/*
- * ARRIVAL CELLS (dsc_groupnorm_silu_nhwc*, dsc_conv3x3_nhwc_f16): an optional block of DSC_ARRIVAL_CELLS_BYTES of
- * device memory that the caller zeroes ONCE and then hands to every call it makes on ONE stream (or one captured
- * graph): the kernels use it as arrival counters (the last workgroup to arrive does the pass that otherwise needs
- * its own launch - the GroupNorm finalize, the split-K sum of the convolution) and leave it ready for the next call
- * (counters back at zero; the GroupNorm barrier generations run on).
- * Two streams that may run concurrently need a block each.  NULL / too small: the multi-launch forms run, the results
- * are the same bit for bit (GroupNorm: see groupnorm_nhwc.hip on its 20 ms waiting bound).
- */
-#define DSC_ARRIVAL_CELLS_BYTES 16384
 int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta,
                             const void* add, int64_t add_row_stride,   /* elements between rows of `add` (>= C) */
                             int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
-                            void* workspace, size_t workspace_bytes, void* arrival_cells, size_t arrival_cells_bytes,
-                            void* stream);
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* The same over the channel concatenation [x1 | x2] that the caller never materialised - the up blocks'
  * `torch.cat([hidden_states, res_hidden_states], dim=1)` in front of every ResNet block (diffusers UpBlock2D /
  * CrossAttnUpBlock2D, reached from reference u_net_condition_modify.py:1274-1302): x1 [B, hw, C1], x2 [B, hw, C - C1],
@@ -233,7 +220,7 @@ int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const voi
 int dsc_groupnorm_silu_nhwc_cat(const void* x1, const void* x2, int C1, void* cat, void* y, const void* gamma,
                                 const void* beta, const void* add, int64_t add_row_stride, int B, int C, int hw,
                                 int groups, float eps, int apply_silu, int dtype, void* workspace, size_t workspace_bytes,
-                                void* arrival_cells, size_t arrival_cells_bytes, void* stream);
+                                void* stream);
 
 /* out[r, c] = a[r, c] + b[r, c] + bias[c] over fp16 [rows, C] (channels-last residual add with the convolution's
  * bias folded in: the ResNet block's `x + conv2(h)` where conv2 ran without its bias).  bias may be NULL. C % 8 == 0. */
@@ -279,14 +266,12 @@ int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
 /* diagnostics: 8 x int64 per workgroup (start / loop start / loop end / end in 100 MHz ticks, the three segment lengths in
  * shader clocks, XCC and HW ids) of every following dsc_conv3x3_nhwc_f16 call go to `device_buffer`; NULL switches it off */
 void dsc_debug_set_conv_stamps(void* device_buffer);
-/* diagnostics: force the weight-tile ring depth (3 or 9 stages); 0 = chosen from the grid size; 100 / 101 = split-K
- * always through the separate sum launch / in the convolution kernel when arrival cells are given (default) */
+/* diagnostics: force the weight-tile ring depth (3 or 9 stages); 0 = chosen from the grid size */
 void dsc_debug_set_conv_ring(int stages);
 size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
 int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                          int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
                          int resample, int out_nchw, int splits, int dtype, void* workspace, size_t workspace_bytes,
-                         void* arrival_cells, size_t arrival_cells_bytes,   /* optional, see ARRIVAL CELLS: split-K without the sum launch */
                          void* stream);
 
 /*

@@ -115,7 +115,7 @@ def test_workspace_slot_and_concat_groupnorm_validation(lib):
     d = ctypes.c_void_p(0x1000)
     cat = lambda **kw: lib.dsc_groupnorm_silu_nhwc_cat(  # noqa: E731
         d, kw.get("x2", ctypes.c_void_p(0x2000)), kw.get("C1", 320), kw.get("cat", ctypes.c_void_p(0x3000)),
-        ctypes.c_void_p(0x4000), d, d, None, 0, 2, kw.get("C", 640), 64, 32, 1e-5, 1, 0, kw.get("ws", None), 0, None, 0, None)
+        ctypes.c_void_p(0x4000), d, d, None, 0, 2, kw.get("C", 640), 64, 32, 1e-5, 1, 0, kw.get("ws", None), 0, None)
     assert cat(x2=None) == -1 and cat(cat=None) == -1
     assert cat(C1=640) == -1 and cat(C1=0) == -1          # both sources must contribute channels
     assert cat(C1=12) == -2                               # 16-byte vectors must not straddle the seam

@@ -96,104 +96,6 @@ def test_groupnorm_of_concatenation(ops, B, C1, C2, h, w, G, act):
     assert (y.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("B,C,h,w,G,act,with_add", [(2, 320, 64, 64, 32, True, True), (2, 640, 64, 64, 32, True, False),
-                                                    (2, 960, 64, 64, 32, True, True), (2, 1920, 32, 32, 32, True, False),
-                                                    (2, 1280, 32, 32, 32, True, True), (2, 2560, 16, 16, 32, True, False),
-                                                    (4, 320, 64, 64, 32, True, True), (8, 640, 32, 32, 32, False, True),
-                                                    (16, 320, 64, 64, 32, True, True), (3, 96, 40, 40, 8, True, True),
-                                                    (1, 320, 96, 96, 32, True, False), (2, 320, 72, 88, 32, True, True),
-                                                    (2, 96, 16, 16, 8, True, True), (1, 24, 9, 11, 3, False, True),
-                                                    (2, 200, 30, 30, 5, True, False)])
-def test_groupnorm_one_launch_with_arrival_cells(ops, B, C, h, w, G, act, with_add):
-    """The one-launch GroupNorm (arrival cells, groupnorm_nhwc.hip gn_nhwc_coop): against the fp32 reference and the
-    multi-launch form; its fallback (waiting workgroups give up at once: dsc_debug_set_gn_mode(5)); the cells are reusable
-    straight away (repeated calls, other shapes in between); shapes it declines (too large) still run with cells given."""
-    from diffusionspatialcontrol_amd import _lib
-    lib = _lib.load_library()
-    g = torch.Generator().manual_seed(B * C + h + 7)
-    x = (torch.randn(B, C, h, w, generator=g) * 1.7 + 0.6).half().cuda().contiguous(memory_format=torch.channels_last)
-    add = (torch.randn(B, C, generator=g) * 0.8).half().cuda() if with_add else None
-    gamma, beta = (torch.randn(C, generator=g) * 0.5 + 1).half().cuda(), (torch.randn(C, generator=g) * 0.3).half().cuda()
-    xin = x.float() + (add.float()[:, :, None, None] if with_add else 0.0)
-    ref = F.group_norm(xin, G, gamma.float(), beta.float(), 1e-5)
-    ref = F.silu(ref) if act else ref
-    plain = ops.groupnorm_silu_nhwc(x, G, gamma, beta, 1e-5, act, add=add)
-    cells = ops.new_arrival_cells(x.device)
-    other = torch.randn(2, 640, 32, 32).half().cuda().contiguous(memory_format=torch.channels_last)
-    with ops.arrival_cells(cells):
-        ys = [ops.groupnorm_silu_nhwc(x, G, gamma, beta, 1e-5, act, add=add)]
-        ops.groupnorm_silu_nhwc(other, 32, torch.ones(640).half().cuda(), torch.zeros(640).half().cuda(), 1e-5, True)
-        ys.append(ops.groupnorm_silu_nhwc(x, G, gamma, beta, 1e-5, act, add=add))
-        lib.dsc_debug_set_gn_mode(5)
-        try:
-            ys.append(ops.groupnorm_silu_nhwc(x, G, gamma, beta, 1e-5, act, add=add))
-        finally:
-            lib.dsc_debug_set_gn_mode(0)
-        ys.append(ops.groupnorm_silu_nhwc(x, G, gamma, beta, 1e-5, act, add=add))
-    torch.cuda.synchronize()
-    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[0], ys[3])              # same launch, same order of sums
-    for y in ys:
-        err = (y.float() - ref).abs()
-        assert err.max().item() < 4e-3 * max(1.0, ref.abs().max().item()), err.max().item()
-        assert err.mean().item() < 4e-4
-        # against the multi-launch form: the fp64 partials are grouped differently -> at most an fp32 ulp in (mean, rstd)
-        assert (y.float() - plain.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
-    c = cells.cpu()
-    assert torch.all(c[0:2 * B:2] == 0), "arrival counters must be back at zero"
-
-
-@pytest.mark.parametrize("B,C1,C2,h,w,G", [(2, 640, 320, 64, 64, 32), (2, 320, 320, 64, 64, 32), (2, 1280, 640, 32, 32, 32),
-                                           (2, 1280, 1280, 16, 16, 32), (2, 64, 32, 16, 16, 8), (3, 40, 24, 5, 7, 8)])
-def test_groupnorm_of_concatenation_one_launch(ops, B, C1, C2, h, w, G):
-    g = torch.Generator().manual_seed(C1 + C2 + h)
-    cl = torch.channels_last
-    x1 = (torch.randn(B, C1, h, w, generator=g) * 1.3 + 0.2).half().cuda().contiguous(memory_format=cl)
-    x2 = (torch.randn(B, C2, h, w, generator=g) * 0.7 - 0.4).half().cuda().contiguous(memory_format=cl)
-    gamma = (torch.randn(C1 + C2, generator=g) * 0.5 + 1).half().cuda()
-    beta = (torch.randn(C1 + C2, generator=g) * 0.3).half().cuda()
-    add = (torch.randn(B, C1 + C2, generator=g) * 0.8).half().cuda()
-    want_cat = torch.cat([x1, x2], dim=1).contiguous(memory_format=cl)
-    cells = ops.new_arrival_cells(x1.device)
-    with ops.arrival_cells(cells):
-        y, cat = ops.groupnorm_silu_nhwc_cat(x1, x2, G, gamma, beta, 1e-5, True, add=add)
-        y_plain = ops.groupnorm_silu_nhwc(want_cat, G, gamma, beta, 1e-5, True, add=add)
-    assert torch.equal(cat, want_cat)
-    if G == 32:
-        assert torch.equal(y, y_plain)        # the same kernel on the materialised concatenation
-    else:                                     # narrow groups: the plain tensor takes the two-pass single-launch kernel
-        assert (y.float() - y_plain.float()).abs().max().item() <= 2e-3 * max(1.0, y_plain.float().abs().max().item())
-    ref = F.silu(F.group_norm(want_cat.float() + add.float()[:, :, None, None], G, gamma.float(), beta.float(), 1e-5))
-    assert (y.float() - ref).abs().max().item() < 4e-3 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.parametrize("B,Cin,Cout,H,W,splits,mode", [
-    (2, 640, 640, 32, 32, 2, ""), (2, 1280, 1280, 16, 16, 0, ""), (2, 2560, 1280, 16, 16, 0, ""), (2, 1280, 1280, 8, 8, 0, ""),
-    (2, 2560, 1280, 8, 8, 0, ""), (3, 128, 64, 8, 8, 2, ""), (2, 192, 64, 24, 48, 3, ""), (2, 1280, 1280, 8, 8, 0, "up"),
-    (2, 640, 640, 32, 32, 5, "s2"), (5, 256, 128, 8, 16, 4, "")])
-def test_conv3x3_split_sum_in_kernel(ops, B, Cin, Cout, H, W, splits, mode):
-    """split-K with arrival cells (the last workgroup of a tile adds the partial tiles): the bytes of the two-launch form,
-    with bias / residual / resampling; the cells are back at zero and reusable"""
-    g = torch.Generator().manual_seed(B * 7 + Cin + Cout + H + W)
-    cl = torch.channels_last
-    kw = {"upsample": True} if mode == "up" else ({"stride2": True} if mode == "s2" else {})
-    oh, ow = (2 * H, 2 * W) if mode == "up" else ((H // 2, W // 2) if mode == "s2" else (H, W))
-    x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=cl)
-    wd = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half().cuda().contiguous(memory_format=cl)
-    b = (torch.randn(Cout, generator=g) * 0.2).half().cuda()
-    r = torch.randn(B, Cout, oh, ow, generator=g).half().cuda().contiguous(memory_format=cl)
-    want = [ops.conv3x3(x, wd, b, splits=splits, **kw), ops.conv3x3(x, wd, b, residual=r, splits=splits, **kw),
-            ops.conv3x3(x, wd, None, splits=splits, **kw)]
-    cells = ops.new_arrival_cells(x.device)
-    with ops.arrival_cells(cells):
-        got = [ops.conv3x3(x, wd, b, splits=splits, **kw), ops.conv3x3(x, wd, b, residual=r, splits=splits, **kw),
-               ops.conv3x3(x, wd, None, splits=splits, **kw)]
-        again = ops.conv3x3(x, wd, b, residual=r, splits=splits, **kw)
-    for a_, b_ in zip(want, got):
-        assert torch.equal(a_, b_)
-    assert torch.equal(again, want[1])
-    assert int(cells.abs().sum().item()) == 0
-
-
 def test_groupnorm_of_concatenation_rejects(ops):
     x1 = torch.randn(1, 12, 4, 4).half().cuda().contiguous(memory_format=torch.channels_last)      # 12 % 8 != 0
     x2 = torch.randn(1, 20, 4, 4).half().cuda().contiguous(memory_format=torch.channels_last)
@@ -353,6 +255,36 @@ def test_conv3x3_upsample(ops, B, C, Cout, h, w):
     assert out.shape == (B, Cout, 2 * h, 2 * w)
     assert torch.all((out.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3)
     assert torch.equal(out, ops.conv3x3(up, wt, b))                        # same sums in the same order
+
+
+@pytest.mark.parametrize("M,N,K,geglu", [(8192, 320, 320, False), (512, 1280, 1280, False), (2048, 640, 2560, False), (130, 1280, 1280, False),
+                                          (77, 320, 768, False), (2048, 5120, 640, True), (512, 10240, 1280, True), (8192, 2560, 320, True)])
+def test_linear_kernel_tilings_agree_bit_for_bit(ops, M, N, K, geglu):
+    """gemm_tn_f16's launch variants (dsc_debug_set_gemm_stages: ring depth 2 / 3, 64- / 128-row tiles, with and without the four
+    DMA-only loader waves) form the same sums in the same order: equal bytes, and right against fp32."""
+    from diffusionspatialcontrol_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.2).half().cuda()
+    r = torch.randn(M, N // 2 if geglu else N, generator=g).half().cuda()
+    saved = (ops.DSC_GEMM_MIN_ROWS, ops.DSC_GEMM_MAX_K, ops.DSC_GEMM_MID_ROWS, ops.DSC_GEMM_MID_K)
+    ops.DSC_GEMM_MIN_ROWS, ops.DSC_GEMM_MAX_K, ops.DSC_GEMM_MID_ROWS, ops.DSC_GEMM_MID_K = 1, 1 << 30, 1, 1 << 30
+    outs = {}
+    try:
+        assert ops.linear_kernel_covers(M, N, K, torch.float16, geglu=geglu)
+        for knob in (0, 90003, 40003, 90002, 91283, 41283) + (() if geglu else (90643, 40643, 90642)):
+            lib.dsc_debug_set_gemm_stages(knob)
+            outs[knob] = ops.linear(x, w, b, geglu=True) if geglu else ops.linear(x, w, b, residual=r)
+    finally:
+        lib.dsc_debug_set_gemm_stages(0)
+        ops.DSC_GEMM_MIN_ROWS, ops.DSC_GEMM_MAX_K, ops.DSC_GEMM_MID_ROWS, ops.DSC_GEMM_MID_K = saved
+    ref = F.linear(x.float(), w.float(), b.float())
+    ref = ref[:, :N // 2] * F.gelu(ref[:, N // 2:]) if geglu else ref + r.float()
+    for knob, o in outs.items():
+        assert torch.equal(o, outs[0]), knob
+    assert torch.all((outs[0].float() - ref).abs() <= 2e-3 * ref.abs() + 3e-3)
 
 
 @pytest.mark.parametrize("M", [1, 2, 5, 8])

@@ -16,8 +16,8 @@ for (M, N, K, geglu) in [(8192, 320, 320, 0), (8192, 2560, 320, 1), (8192, 320, 
     ref = F.linear(x.float(), w.float(), b.float())
     ref = (ref[:, :N // 2] * F.gelu(ref[:, N // 2:])) if geglu else ref + r.float()
     line = []
-    for stg in (3, 40003, 643, 40643):
-        if geglu and stg in (643, 40643):
+    for stg in (90003, 40003, 90643, 40643):     # 9....: never loader waves, 4....: always
+        if geglu and stg in (90643, 40643):
             continue
         lib.dsc_debug_set_gemm_stages(stg)
         fn = (lambda: ops.linear(x, w, b, geglu=True)) if geglu else (lambda: ops.linear(x, w, b, residual=r))
