@@ -429,6 +429,7 @@ int tile_width(int H, int W) {
 //   fixed     5 (launch, prologue, epilogue)
 //   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
 // e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
+double g_conv_small_step = 0.26;   // us per step of a grid of <= 256 workgroups (dsc_debug_set_conv_ring(200 + hundredths))
 int auto_splits(int tiles, int nc, long long npix, int cout) {
     int best = 1;
     double best_t = 1e30;
@@ -436,7 +437,7 @@ int auto_splits(int tiles, int nc, long long npix, int cout) {
         if (nc % s != 0) continue;
         const long long wgs = (long long)tiles * s;
         if (s > 1 && wgs > 1024) break;
-        const double load = wgs <= 256 ? 1.0 : (wgs <= 512 ? 1.15 : 1.15 * (double)wgs / 512.0);
+        const double load = wgs <= 256 ? g_conv_small_step / 0.26 : (wgs <= 512 ? 1.15 : 1.15 * (double)wgs / 512.0);
         double t = 9.0 * nc / s * 0.26 * load + 5.0;
         if (s > 1) t += 4.0 + (double)s * (double)npix * cout * 8.0 / 3.0e6;
         if (t < best_t) { best_t = t; best = s; }
@@ -465,7 +466,10 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
-extern "C" void dsc_debug_set_conv_ring(int stages) { g_conv_ring = stages; }
+extern "C" void dsc_debug_set_conv_ring(int stages) {
+    if (stages >= 200) g_conv_small_step = (stages - 200) / 100.0;
+    else g_conv_ring = stages;
+}
 
 extern "C" int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout) {
     ConvParams p{};
@@ -524,10 +528,13 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     }
     const int total = p.mt * p.nt * p.splits;
     const dim3 grid(((total + 7) / 8) * 8), block(T);
-    // 3 stages unless forced: the 9-stage ring (one workgroup per CU) measured slower on every UNet shape
-    // (tools/mb_conv3.py: 320->320 @64x64 23.6 us vs 31.4 us) - a step does not wait for the DMA latency
+    // Ring depth.  The 9-stage ring needs the whole LDS (one workgroup per CU), so every grid of more than 256 workgroups loses
+    // its second co-resident workgroup to it (320->320 @64x64 23.6 vs 31.4 us back to back, 29.7 vs 38.9 in the step).  A grid
+    // that has at most one workgroup per CU anyway gains: in the step its weight tiles come from HBM, and two tiles in flight
+    // (three stages) at ~550 cycles per step are less than that latency - 160 workgroups 32.9 -> 24.3 us, 200 (8-wide tiles)
+    // 15.4 -> 14.2, 64 22.6 -> 20.2 (tools/ab_step.sh, DSC_CONV_RING=3 / 9; the warm micro-benchmark shows no difference).
     int ring = g_conv_ring;
-    if (ring != 3 && ring != 9) ring = 3;
+    if (ring != 3 && ring != 9) ring = total <= 256 ? 9 : 3;
     if (tw == 16) {
         if (ring == 9) DSC_LAUNCH((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
         else DSC_LAUNCH((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);
