@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="generations in flight per GPU: N host threads, each with its own stream and generation slot (static "
                          "buffers, captured step, packed K/V, library workspace); every generation is still one batch-1 image")
+    ap.add_argument("--tuning-profile", choices=["auto", "latency", "throughput"], default="auto",
+                    help="launch rules (dsc_set_tuning_profile): auto = 'latency' for the one-at-a-time leg, 'throughput' for the "
+                         "generations in flight (each slot re-captures its step, untimed); or one profile for every leg (A/B)")
     ap.add_argument("--stall-seconds", type=float, default=120.0,
                     help="in-flight leg: no generation completed for this long -> print the line (status: stalled, value = the "
                          "one-at-a-time figure) and exit with status 3")
@@ -362,6 +365,7 @@ def main():
         return out
 
     out = None
+    ops.set_tuning_profile("latency" if a.tuning_profile == "auto" else a.tuning_profile)
     nfl = 1 if (a.decode or a.no_graph) else max(1, a.in_flight)     # slots exist for the captured denoising loop
     if nfl > 4:
         raise SystemExit("--in-flight: at most 4 generation slots (dsc_set_workspace_slot)")
@@ -461,6 +465,14 @@ def main():
                 "max_abs_err": round(err.max().item(), 5), "mean_abs_err": round(err.mean().item(), 6),
                 "ref_max_abs": round(ref.abs().max().item(), 4), "note": "latents after the sampled steps: fp16 HIP path vs fp32 oracle"}
     if nfl > 1:
+        # the launch rules for generations that SHARE the chip (include/dsc_hip.h, dsc_set_tuning_profile): the legs above ran
+        # under "latency"; every slot re-captures its step under "throughput" here, outside the timed region
+        if a.tuning_profile == "auto":
+            ops.set_tuning_profile("throughput")
+            for s_i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    generate(s_i)
+                torch.cuda.synchronize()
         progress = [0, time.monotonic()]
         outs, errs = [None] * nfl, []
         todo, todo_lock = iter(range(a.steps)), threading.Lock()
@@ -510,6 +522,8 @@ def main():
                                                "note": "the same K generations with one in flight (latency of one image)"}
             res["value"], res["ms_per_step"] = round(images / dt, 4), round(dt / a.steps * 1e3, 2)
             res["config"].update({"generations_in_flight": nfl, "slots_equal_one_at_a_time": slots_agree,
+                                  "tuning_profile": {"one_generation_at_a_time": "latency" if a.tuning_profile == "auto" else a.tuning_profile,
+                                                     "in_flight": ops.tuning_profile()},
                                   "per_rank_images_per_s": rates_fl, "max_over_ranks_s": round(dt, 4),
                                   "outputs_finite": finite and all(bool(torch.isfinite(o).all().item()) for o in slot_outs),
                                   "workload": res["config"]["workload"].replace("1 generation(s) in flight", f"{nfl} generation(s) in flight")})

@@ -64,6 +64,8 @@ _SIGNATURES = {
     "dsc_groupnorm_silu_nhwc_cat": (ctypes.c_int, [_vp, _vp, ctypes.c_int] + [_vp] * 5 + [ctypes.c_int64] + [ctypes.c_int] * 4 +
                                     [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t, _vp]),
     "dsc_set_workspace_slot": (ctypes.c_int, [ctypes.c_int]),
+    "dsc_set_tuning_profile": (ctypes.c_int, [ctypes.c_int]),
+    "dsc_get_tuning_profile": (ctypes.c_int, []),
     "dsc_linear_lt_stats": (None, [_vp]),
     "dsc_add_bias_residual": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_linear_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +

@@ -13,3 +13,12 @@ extern "C" const char* dsc_status_string(int status) {
         default: return "unknown status";
     }
 }
+
+// Tuning profile (dsc_set_tuning_profile): read by the launch rules of conv3x3.hip and gemm.hip at launch (= capture) time.
+int g_dsc_tuning_profile = DSC_TUNE_LATENCY;
+extern "C" int dsc_set_tuning_profile(int profile) {
+    if (profile != DSC_TUNE_LATENCY && profile != DSC_TUNE_THROUGHPUT) return DSC_ERR_BAD_ARG;
+    g_dsc_tuning_profile = profile;
+    return DSC_OK;
+}
+extern "C" int dsc_get_tuning_profile(void) { return g_dsc_tuning_profile; }

@@ -23,6 +23,8 @@
 #include "dsc_hip.h"
 #include <type_traits>
 
+extern int g_dsc_tuning_profile;     // c_api.hip
+
 namespace {
 
 constexpr int BM = 128, BN = 64, BK = 64, T = 256;
@@ -534,7 +536,9 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     // (three stages) at ~550 cycles per step are less than that latency - 160 workgroups 32.9 -> 24.3 us, 200 (8-wide tiles)
     // 15.4 -> 14.2, 64 22.6 -> 20.2 (tools/ab_step.sh, DSC_CONV_RING=3 / 9; the warm micro-benchmark shows no difference).
     int ring = g_conv_ring;
-    if (ring != 3 && ring != 9) ring = total <= 256 ? 9 : 3;
+    // ... and only while this stream owns the chip: with a second generation in flight the whole-LDS workgroups keep the other
+    // stream's kernels off their CUs (dsc_set_tuning_profile)
+    if (ring != 3 && ring != 9) ring = (total <= 256 && g_dsc_tuning_profile == DSC_TUNE_LATENCY) ? 9 : 3;
     if (tw == 16) {
         if (ring == 9) DSC_LAUNCH((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
         else DSC_LAUNCH((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);

@@ -29,6 +29,8 @@
 #include "dsc_common.h"
 #include "dsc_hip.h"
 
+extern int g_dsc_tuning_profile;     // c_api.hip
+
 namespace {
 
 constexpr int BN = 64, BK = 64, T = 256;
@@ -442,7 +444,8 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // Four DMA-only loader waves beside the four computing ones: in the step 1-3 % on the 64-row-tile GEMMs (10.7 -> 10.6,
     // 9.6 -> 9.3, 8.9 -> 8.7 us; 5-20 % back to back with warm weights, tools/chk_gemm_loader.py), while the 128-row tiles
     // of the big grids keep the two-stage ring and three workgroups per CU (with loaders and three stages: GEGLU 29.7 -> 31.9 us)
-    if (g_gemm_loaders == 4 || (g_gemm_loaders == 0 && bm == 64 && stages == 3)) {
+    // - under DSC_TUNE_LATENCY only: eight-wave workgroups cost the other stream's kernels their wave slots
+    if (g_gemm_loaders == 4 || (g_gemm_loaders == 0 && bm == 64 && stages == 3 && g_dsc_tuning_profile == DSC_TUNE_LATENCY)) {
         lds = (size_t)3 * stage_halves(bm) * sizeof(half_t);
         if (lds < epi) lds = epi;
         const dim3 block8(T + 256);

@@ -1034,7 +1034,7 @@ class StableDiffusionPipeline:
             comp_cpu is None or self._weight_func_key(weight_func) != "default" or text.shape[1] > 384
             or not self._all_cross_attention_packable())         # (<= 384 text keys: the chunked prepared-operand kernels)
         if (st is not None and (st["compressed"] is None) == (comp_cpu is None)
-                and (st["dense"] is None) == (not need_dense)):
+                and (st["dense"] is None) == (not need_dense) and st["profile"] == ops.tuning_profile()):
             done = st.get("done")
             if done is not None:         # the slot's buffers may last have been driven from another stream
                 torch.cuda.current_stream(text.device).wait_event(done)
@@ -1055,6 +1055,7 @@ class StableDiffusionPipeline:
             "text": text.clone(),
             "compressed": None, "dense": None,
             "weight_func": weight_func,          # kept alive: the key holds its id
+            "profile": ops.tuning_profile(),     # the launch rules baked into the capture (ops.set_tuning_profile)
             "image_embeds": None if ack is None else [e.clone() for e in ack["image_embeds"]],
         }
         if comp_cpu is not None:

@@ -37,6 +37,23 @@ def _workspace(device, nbytes):
     return torch.empty(max(nbytes, 16) // 8 + 1, dtype=torch.float64, device=device)
 
 
+TUNING_PROFILES = {"latency": 0, "throughput": 1}       # DSC_TUNE_LATENCY / DSC_TUNE_THROUGHPUT (include/dsc_hip.h)
+
+
+def set_tuning_profile(name):
+    """launch rules for one generation at a time ("latency", the default) or for several generations in flight on their
+    own streams ("throughput") - dsc_set_tuning_profile.  Read at launch time: a step graph keeps the profile it was
+    captured under, and the pipeline re-captures a slot's step when the profile has changed since."""
+    if name not in TUNING_PROFILES:
+        raise ValueError(f"tuning profile must be one of {sorted(TUNING_PROFILES)}")
+    _lib.check(_lib.load_library().dsc_set_tuning_profile(TUNING_PROFILES[name]), "dsc_set_tuning_profile")
+
+
+def tuning_profile():
+    v = _lib.load_library().dsc_get_tuning_profile()
+    return next(k for k, x in TUNING_PROFILES.items() if x == v)
+
+
 def _blhd_strides(t, layout):
     """(sb, sl, sh) element strides of a [B, L, H, d]-addressable tensor.
     layout 'blc': t is [B, L, H*d] (or a view [B, L, H, d]);  'bhld': t is [B, H, L, d]."""

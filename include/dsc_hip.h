@@ -327,6 +327,21 @@ int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void
  * streams drives each from its own thread / slot, so that neither the eager GEMMs nor the ones baked into the two captured
  * step graphs share a workspace.  Thread-local; returns DSC_ERR_BAD_ARG outside 0..3. */
 int dsc_set_workspace_slot(int slot);
+/*
+ * Tuning profile of the launch rules, process-wide, read when a kernel is LAUNCHED (so a captured graph keeps the profile it
+ * was captured under):
+ *   DSC_TUNE_LATENCY     one generation at a time owns the chip (default): kernels may take a whole CU each - the 3x3
+ *                        convolution's nine-stage weight ring for grids of <= 256 workgroups (all of a CU's LDS), the GEMM's
+ *                        four extra DMA-only loader waves for its 64-row tiles.  +1.5 % images/s one at a time.
+ *   DSC_TUNE_THROUGHPUT  several generations share the chip on their own streams: the three-stage ring / four-wave forms,
+ *                        which leave room for the other stream's workgroups on the same CU.  +3 % images/s with two generations
+ *                        in flight against the latency rules (7 interleaved runs each on one box: 10.81 vs 10.46).
+ * The two give equal bytes.  Returns DSC_ERR_BAD_ARG for any other value.
+ */
+#define DSC_TUNE_LATENCY 0
+#define DSC_TUNE_THROUGHPUT 1
+int dsc_set_tuning_profile(int profile);
+int dsc_get_tuning_profile(void);
 /* Diagnostic: out[0] = shapes planned so far, out[1] = library candidate algorithms the heuristic offered, out[2] = how
  * many of those need a workspace (stream-K / split-K kernels whose workgroups wait on each other's partial tiles) and were
  * therefore NOT eligible: dsc_linear_lt_f16 only ever runs workspace-free algorithms, which finish under any residency. */

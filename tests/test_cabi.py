@@ -121,3 +121,11 @@ def test_workspace_slot_and_concat_groupnorm_validation(lib):
     assert cat(C1=12) == -2                               # 16-byte vectors must not straddle the seam
     assert cat(cat=d) == -2                               # the concatenation must not alias a source
     assert cat() == -3                                    # valid arguments, no workspace
+
+
+def test_tuning_profile_entry_points(lib):
+    """dsc_set_tuning_profile / dsc_get_tuning_profile: two profiles, anything else is a bad argument and changes nothing"""
+    assert lib.dsc_get_tuning_profile() == 0                                    # DSC_TUNE_LATENCY is the default
+    assert lib.dsc_set_tuning_profile(1) == 0 and lib.dsc_get_tuning_profile() == 1
+    assert lib.dsc_set_tuning_profile(2) == -1 and lib.dsc_set_tuning_profile(-1) == -1 and lib.dsc_get_tuning_profile() == 1
+    assert lib.dsc_set_tuning_profile(0) == 0 and lib.dsc_get_tuning_profile() == 0

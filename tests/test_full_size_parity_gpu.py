@@ -349,3 +349,28 @@ def test_config5_sdxl_two_images_per_gpu():
             exp = torch.nn.functional.linear(exp, to_out.weight.float().cpu(), to_out.bias.float().cpu())
             err = (got[rows].float().cpu() - exp).abs()
             assert err.max().item() < 8e-3 * max(1.0, exp.abs().max().item()), (L, i, err.max().item())
+
+
+def test_step_is_recaptured_when_the_tuning_profile_changes():
+    """a slot's captured step keeps the launch rules it was captured under; after ops.set_tuning_profile the next generation
+    re-captures (st["profile"]) and gives the same latents (the profiles' kernels give equal bytes,
+    test_conv3x3_and_gemm_profiles_give_equal_bytes; the toy widths run MIOpen's atomic convolutions, hence a tolerance here)"""
+    from diffusionspatialcontrol_amd import ops
+    wf = lambda w, s, qk: w * s * qk.std()                                     # noqa: E731
+    rs = _random_tables(3, 8)
+    cfg, pipe = _tiny_pipe()
+    try:
+        ops.set_tuning_profile("latency")
+        a = _run_tiny(pipe, cfg, rs, wf)
+        st_a = next(iter(pipe._graphs.values()))
+        assert st_a["profile"] == "latency"
+        b = _run_tiny(pipe, cfg, rs, wf)
+        assert next(iter(pipe._graphs.values())) is st_a                        # same shapes, same profile: the same capture
+        ops.set_tuning_profile("throughput")
+        c = _run_tiny(pipe, cfg, rs, wf)
+        st_c = next(iter(pipe._graphs.values()))
+        assert st_c is not st_a and st_c["profile"] == "throughput" and len(pipe._graphs) == 1
+    finally:
+        ops.set_tuning_profile("latency")
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() < 2e-2 * scale and (a - c).abs().max().item() < 2e-2 * scale

@@ -240,6 +240,37 @@ def test_conv3x3_kernel(ops, B, Cin, Cout, H, W, splits):
     assert torch.all((oi - ri).abs() <= 1e-3 * ri.abs() + 1e-6)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 1280, 1280, 16, 16), (2, 1280, 1280, 8, 8), (2, 640, 640, 32, 32), (1, 64, 128, 16, 24)])
+def test_conv3x3_and_gemm_profiles_give_equal_bytes(ops, B, Cin, Cout, H, W):
+    """dsc_set_tuning_profile: the latency rules (nine-stage convolution ring for small grids, GEMM loader waves) and the
+    throughput rules launch different kernels that add in the same order - equal bytes; so does a forced ring depth"""
+    from diffusionspatialcontrol_amd import _lib
+    lib = _lib.load_library()
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    cl = torch.channels_last
+    x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=cl)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half().cuda().contiguous(memory_format=cl)
+    b = (torch.randn(Cout, generator=g) * 0.2).half().cuda()
+    xt = torch.randn(B * H * W, Cin, generator=g).half().cuda()
+    wt = (torch.randn(Cout, Cin, generator=g) / math.sqrt(Cin)).half().cuda()
+    outs = {}
+    try:
+        for prof in ("latency", "throughput"):
+            ops.set_tuning_profile(prof)
+            assert ops.tuning_profile() == prof
+            outs[prof] = (ops.conv3x3(x, w, b), ops.linear(xt, wt, b) if ops.linear_kernel_covers(B * H * W, Cout, Cin, torch.float16) else None)
+        for ring in (3, 9):
+            lib.dsc_debug_set_conv_ring(ring)
+            outs[ring] = (ops.conv3x3(x, w, b), None)
+    finally:
+        lib.dsc_debug_set_conv_ring(0)
+        ops.set_tuning_profile("latency")
+    for k in ("throughput", 3, 9):
+        assert torch.equal(outs[k][0], outs["latency"][0]), k
+    if outs["latency"][1] is not None:
+        assert torch.equal(outs["throughput"][1], outs["latency"][1])
+
+
 @pytest.mark.parametrize("B,C,Cout,h,w", [(2, 1280, 1280, 8, 8), (2, 640, 640, 32, 32), (1, 64, 64, 4, 12), (3, 128, 64, 4, 4)])
 def test_conv3x3_upsample(ops, B, C, Cout, h, w):
     """Upsample2D: nearest 2x + conv (diffusers) == the convolution reading the small image through the upsampling map"""
