@@ -117,6 +117,8 @@ def load_library():
         fn.restype, fn.argtypes = res, args
     if os.environ.get("DSC_SA_VARIANT"):                       # A/B switch: force one tiling of the flash self-attention kernel
         lib.dsc_debug_set_self_attn_variant(int(os.environ["DSC_SA_VARIANT"]))
+    if os.environ.get("DSC_TUNING_PROFILE"):                   # latency (default) / throughput: dsc_set_tuning_profile at load time
+        lib.dsc_set_tuning_profile({"latency": 0, "throughput": 1}[os.environ["DSC_TUNING_PROFILE"]])
     if os.environ.get("DSC_CONV_RING"):                        # A/B switch: weight-tile ring depth of the 3x3 convolution (3 / 9)
         lib.dsc_debug_set_conv_ring(int(os.environ["DSC_CONV_RING"]))
     if os.environ.get("DSC_GN_MODE"):                          # A/B switch: GroupNorm kernel selection (dsc_debug_set_gn_mode)

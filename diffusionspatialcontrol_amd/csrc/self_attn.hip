@@ -484,7 +484,10 @@ template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
     constexpr int MW = NK <= 5 ? 2 : 1;                       // waves per SIMD the registers allow: 256 / 512 per wave
     constexpr int NL = NK <= 4 ? NK : 3;                      // (instantiation guards: the loader kernels exist for NK <= 4)
-    const int v = g_sa_variant;
+    // (A/B in the step: 100 + v applies v to the d = 40 level only, 200 = the other levels without their loader kernels)
+    const bool d40 = NK == 3 && p.d == 40;
+    const int v = g_sa_variant >= 200 ? 0 : (g_sa_variant >= 100 ? (d40 ? g_sa_variant - 100 : 0) : g_sa_variant);
+    const bool small_loaders = g_sa_variant != 200;
     const long long wg8 = (long long)p.Bc * p.H * ((p.L + 255) / 256);
     const long long wg4 = (long long)p.Bc * p.H * ((p.L + 127) / 128);
     if (NK <= 4) {
@@ -519,7 +522,7 @@ int launch_nk(const SaParams& p, hipStream_t st) {
     if (v == 15) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 2, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
     if (v == 16) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 4, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
     // measured (tools/mb_sa.py): d = 80 @ L = 1024 21.4 -> 15.1 us, d = 160 @ L = 256 16.5 -> 11.9 us, @ L = 64 8.6 -> 6.8 us
-    if (v == 0 && NK >= 5 && wg4 < 256) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 2, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
+    if (v == 0 && NK >= 5 && wg4 < 256 && small_loaders) return NK <= 8 ? launch<(NK <= 8 ? NK : 3), 2, 2, 0, 4>(p, st) : launch<NK, 2, 1, 0, 2>(p, st);
     if (NK == 5 && ((v == 0 && wg8 >= 512) || v == 2)) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
     if (NK <= 4 && v == 2) return launch<(NK <= 5 ? NK : 3), 8, 2>(p, st);
     if (wg4 >= 256 || v == 1) return launch<NK, 4, MW>(p, st);
