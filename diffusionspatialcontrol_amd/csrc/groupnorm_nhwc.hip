@@ -4,14 +4,14 @@
 // EVERY row: the statistics are column sums.  A workgroup owns a chunk of rows of one image and ALL groups:
 // thread t reads the fixed 16-byte channel vector c8 = t % (C/8) of rows slice, slice+k, ... (k = row slices per
 // workgroup), so every load/store is a coalesced 16-byte access and the per-channel constants stay in registers.
-//   launch 1 gn_nhwc_stats    : per-thread channel sums -> LDS [k][C] -> per-channel -> per-group (sum, sumsq) in
-//                               fp64 -> partials[b][chunk][g]
-//   launch 2 gn_nhwc_finalize : one wave per (image, group) adds the chunk partials -> (mean, rstd)[b][g]; skipped for
-//                               tensors <= 3 MB, whose statistics pass is capped at 32 chunks per image so that
-//                               every apply workgroup can add the partials itself
-//                               Without it every apply workgroup re-read all nchunk x G partials (64 KB, more than
-//                               its own 40 KB of activations)
-//   launch 3 gn_nhwc_apply    : folds mean/rstd/gamma/beta(/add) into one scale+shift per channel, streams its rows:
+//   launch 1 gn_nhwc_stats    : workgroup = (image, row chunk, channel slab of whole groups): per-thread channel sums -> LDS
+//                               [slices][slab] -> per-channel -> per-group (sum, sumsq) in fp64 -> partials[b][chunk][g].
+//                               At most 32 row chunks per image; the slabs supply the rest of the parallelism.
+//   (gn_nhwc_finalize         : one wave per (image, group) adds the chunk partials -> (mean, rstd)[b][g] - only in the
+//                               diagnostic three-launch form (mode 4) now: before the slabs a large tensor needed ~256 row
+//                               chunks per image to fill the chip, too many for every apply workgroup to re-add)
+//   launch 2 gn_nhwc_apply    : adds the <= 32 partial rows of its image itself (<= 16 KB of L2 reads), folds
+//                               mean/rstd/gamma/beta(/add) into one scale+shift per channel, streams its rows:
 //                               y = silu(x*sc + sh)
 // HBM-bound: algorithmic bytes = 2 * B*hw*C*2 (read + write); the second read hits L2 / Infinity Cache.
 #include "dsc_common.h"
@@ -28,6 +28,7 @@ struct GnN {
     int B, HW, C, G, cpg, cv, k, nchunk, rows;       // statistics pass: nchunk row chunks of `rows` rows per image
     int anchunk, arows;                               // apply pass: its own (finer) chunking
     int inline_stats;                                 // 1: the apply workgroups reduce the chunk partials themselves (no finalize launch)
+    int scv, nslab, sk;                               // statistics pass: channel slabs of scv vectors (whole groups), sk row slices per workgroup
     long long add_stride;
     float eps; int silu;
     // concatenation mode (dsc_groupnorm_silu_nhwc_cat): the input is the channel concatenation [x | x2] (C1 channels from
@@ -47,55 +48,70 @@ __device__ __forceinline__ h8_t gn_load(const GnN& p, int b, int pix, int c) {
 
 __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ssum = reinterpret_cast<float*>(smem);            // [k][C]
-    float* ssq = ssum + p.k * p.C;                           // [k][C]
-    const int b = blockIdx.x / p.nchunk, chunk = blockIdx.x % p.nchunk;
-    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
+    // workgroup = (image, row chunk, channel slab); a slab is scv 16-byte vectors = whole groups, so the workgroup owns its
+    // groups' partial sums over its rows.  Slabs are the second axis of parallelism: few row chunks (<= 32 partial rows for
+    // the apply pass to add up itself, no finalize launch) and still a chip-filling number of workgroups.
+    const int slab = blockIdx.x % p.nslab;
+    const int bc = blockIdx.x / p.nslab;
+    const int b = bc / p.nchunk, chunk = bc % p.nchunk;
+    const int v0 = slab * p.scv;                              // first vector of the slab
+    const int sw = min(p.scv, p.cv - v0);                     // this slab's width in vectors (the last one may be narrower)
+    const int SC = p.scv * 8;                                 // LDS row pitch in channels
+    float* ssum = reinterpret_cast<float*>(smem);            // [sk][SC]
+    float* ssq = ssum + p.sk * SC;                           // [sk][SC]
+    const int lv = threadIdx.x % p.scv, slice = threadIdx.x / p.scv;
+    const bool live = lv < sw;
+    const int c8 = v0 + lv;
     const int r0 = chunk * p.rows, r1 = min(r0 + p.rows, p.HW);
     float s[8], q[8], ad[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; ad[j] = 0.f; }
-    if (p.add) {
-        const h8_t a = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
+    if (live) {
+        if (p.add) {
+            const h8_t a = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ad[j] = (float)a[j];
-    }
-    // this thread's channel vector lives in one source for all rows: (base, row stride) fixed up front
-    const half_t* base = p.x + (long long)b * p.HW * p.C + c8 * 8;
-    int rs = p.C;
-    half_t* cdst = nullptr;
-    if (p.x2) {
-        const int c2 = p.C - p.C1;
-        if (c8 * 8 < p.C1) { base = p.x + (long long)b * p.HW * p.C1 + c8 * 8; rs = p.C1; }
-        else { base = p.x2 + (long long)b * p.HW * c2 + (c8 * 8 - p.C1); rs = c2; }
-        cdst = p.cat + (long long)b * p.HW * p.C + c8 * 8;
-    }
-    for (int row = r0 + slice; row < r1; row += p.k) {
-        const h8_t v = *reinterpret_cast<const h8_t*>(base + (long long)row * rs);
-        if (cdst) *reinterpret_cast<h8_t*>(cdst + (long long)row * p.C) = v;
+            for (int j = 0; j < 8; ++j) ad[j] = (float)a[j];
+        }
+        // this thread's channel vector lives in one source for all rows: (base, row stride) fixed up front
+        const half_t* base = p.x + (long long)b * p.HW * p.C + c8 * 8;
+        int rs = p.C;
+        half_t* cdst = nullptr;
+        if (p.x2) {
+            const int c2 = p.C - p.C1;
+            if (c8 * 8 < p.C1) { base = p.x + (long long)b * p.HW * p.C1 + c8 * 8; rs = p.C1; }
+            else { base = p.x2 + (long long)b * p.HW * c2 + (c8 * 8 - p.C1); rs = c2; }
+            cdst = p.cat + (long long)b * p.HW * p.C + c8 * 8;
+        }
+        for (int row = r0 + slice; row < r1; row += p.sk) {
+            const h8_t v = *reinterpret_cast<const h8_t*>(base + (long long)row * rs);
+            if (cdst) *reinterpret_cast<h8_t*>(cdst + (long long)row * p.C) = v;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + ad[j]; s[j] += f; q[j] += f * f; }
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + ad[j]; s[j] += f; q[j] += f * f; }
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { ssum[slice * p.C + c8 * 8 + j] = s[j]; ssq[slice * p.C + c8 * 8 + j] = q[j]; }
+    for (int j = 0; j < 8; ++j) { ssum[slice * SC + lv * 8 + j] = s[j]; ssq[slice * SC + lv * 8 + j] = q[j]; }
     __syncthreads();
-    // per-channel totals over the k slices (threads stride the channels, fixed order, fp64) into tot[C][2] behind the
-    // slice sums, then per-group totals over the cpg channels: two short dependent chains (k, cpg) instead of one of
-    // k * cpg fp64 adds on 32 threads
-    double* tot = reinterpret_cast<double*>(ssq + p.k * p.C);
-    if (p.k > 1) {                                            // one slice: the group sum reads the slice values directly
-        for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    // per-channel totals over the sk slices (threads stride the channels, fixed order, fp64) into tot[SC][2] behind the
+    // slice sums, then per-group totals over the cpg channels: two short dependent chains (sk, cpg) instead of one of
+    // sk * cpg fp64 adds
+    double* tot = reinterpret_cast<double*>(ssq + p.sk * SC);
+    const int nch = sw * 8;                                   // channels of this slab
+    if (p.sk > 1) {                                           // one slice: the group sum reads the slice values directly
+        for (int c = threadIdx.x; c < nch; c += blockDim.x) {
             double c1 = 0.0, c2 = 0.0;
-            for (int sl = 0; sl < p.k; ++sl) { c1 += (double)ssum[sl * p.C + c]; c2 += (double)ssq[sl * p.C + c]; }
+            for (int sl = 0; sl < p.sk; ++sl) { c1 += (double)ssum[sl * SC + c]; c2 += (double)ssq[sl * SC + c]; }
             tot[2 * c] = c1; tot[2 * c + 1] = c2;
         }
         __syncthreads();
     }
-    if (threadIdx.x < p.G) {
-        const int g = threadIdx.x;
+    const int ng = nch / p.cpg;                               // groups of this slab
+    if (threadIdx.x < ng) {
+        const int gl = threadIdx.x;
         double a1 = 0.0, a2 = 0.0;
-        if (p.k > 1) for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += tot[2 * c]; a2 += tot[2 * c + 1]; }
-        else for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) { a1 += (double)ssum[c]; a2 += (double)ssq[c]; }
+        if (p.sk > 1) for (int c = gl * p.cpg; c < (gl + 1) * p.cpg; ++c) { a1 += tot[2 * c]; a2 += tot[2 * c + 1]; }
+        else for (int c = gl * p.cpg; c < (gl + 1) * p.cpg; ++c) { a1 += (double)ssum[c]; a2 += (double)ssq[c]; }
+        const int g = v0 * 8 / p.cpg + gl;
         double* dst = p.partials + (((long long)b * p.nchunk + chunk) * p.G + g) * 2;
         dst[0] = a1; dst[1] = a2;
     }
@@ -374,6 +390,8 @@ __global__ __launch_bounds__(T) void gn_nhwc_bundle(GnN p, GnBundle q) {
     }
 }
 
+int g_gn_slabs = 1;  // diagnostics (dsc_debug_set_gn_mode(10 / 11)): 0 = one channel slab per statistics workgroup
+
 // bundle geometry for T threads and NV vectors per thread; false when the image does not fit
 bool bundle_plan(const GnN& p, int T, int NV, GnBundle* q) {
     int gb = 1;
@@ -401,16 +419,27 @@ bool plan(GnN& p) {
     if (nchunk < 1) nchunk = 1;
     p.arows = (p.HW + nchunk - 1) / nchunk;
     p.anchunk = (p.HW + p.arows - 1) / p.arows;
-    // Small tensors (<= 3 MB): at most 32 statistics chunks per image and the apply workgroups add the partials
-    // themselves - two launches.  Larger ones keep the fine chunking (the statistics pass needs the whole chip) and the
-    // separate finalize launch (measured, tools/mb_gn.py: 640ch @64x64 18.1 us with three launches, 23.9 with two).
-    if ((long long)p.B * p.HW * p.C * 2 <= 3ll << 20) {
-        const int sch = p.anchunk < 32 ? p.anchunk : 32;
+    // Statistics pass: at most 32 row chunks per image (every apply workgroup adds the <= 32 partial rows itself: <= 16 KB
+    // of L2 reads, no finalize launch) times as many channel slabs (whole groups, whole 16-byte vectors) as fill the chip.
+    // Before the slabs a large tensor needed the fine row chunking to occupy the chip, hence ~256 partial rows per image and
+    // a finalize launch in between (640ch @64x64: 18.1 us with three launches against 23.9 with two and no slabs).
+    {
+        const int sch = p.anchunk < 32 ? p.anchunk : 32;          // (16 row chunks: the same GroupNorm time per step, 8: +5 %)
         p.rows = (p.HW + sch - 1) / sch;
         p.nchunk = (p.HW + p.rows - 1) / p.rows;
         p.inline_stats = 1;
-    } else {
-        p.rows = p.arows; p.nchunk = p.anchunk; p.inline_stats = 0;
+        int unit = 1;                                        // vectors per smallest slab: lcm(cpg, 8) channels
+        while ((unit * 8) % p.cpg != 0) ++unit;
+        const int units = p.cv / unit;
+        int want = 256 / (p.B * p.nchunk);                   // slabs that bring the grid to ~256 workgroups
+        if (want < 1 || g_gn_slabs == 0) want = 1;
+        if (want > units) want = units;
+        const int per = (units + want - 1) / want;
+        p.scv = per * unit;
+        p.nslab = (p.cv + p.scv - 1) / p.scv;
+        p.sk = 256 / p.scv;
+        if (p.sk < 1) p.sk = 1;
+        while (p.scv * p.sk < p.scv * 8 / p.cpg) ++p.sk;     // >= as many threads as groups in a slab
     }
     return true;
 }
@@ -448,7 +477,10 @@ extern "C" int dsc_add_bias_residual(const void* a, const void* b, const void* b
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
-extern "C" void dsc_debug_set_gn_mode(int mode) { g_gn_mode = mode; }
+extern "C" void dsc_debug_set_gn_mode(int mode) {
+    if (mode == 10 || mode == 11) g_gn_slabs = mode - 10;      // 10: one channel slab per statistics workgroup, 11: slabs (default)
+    else g_gn_mode = mode;
+}
 
 extern "C" size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int groups) {
     GnN p{};
@@ -520,15 +552,16 @@ int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, con
         }
     }
     const dim3 block(p.cv * p.k);
-    if (g_gn_mode == 4) {                                        // diagnostics: the three-launch form
+    if (g_gn_mode == 4) {                                        // diagnostics: the three-launch form (fine row chunks, no slabs)
         p.rows = p.arows; p.nchunk = p.anchunk; p.inline_stats = 0;
+        p.scv = p.cv; p.nslab = 1; p.sk = p.k;
     }
-    const size_t stats_lds = (size_t)2 * p.k * C * sizeof(float) + (size_t)2 * C * sizeof(double);
+    const size_t stats_lds = (size_t)2 * p.sk * p.scv * 8 * sizeof(float) + (size_t)2 * p.scv * 8 * sizeof(double);
     if (stats_lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_nhwc_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     }
-    DSC_LAUNCH(gn_nhwc_stats, dim3(B * p.nchunk), block, stats_lds, st, p);
+    DSC_LAUNCH(gn_nhwc_stats, dim3(B * p.nchunk * p.nslab), dim3(p.scv * p.sk), stats_lds, st, p);
     if (!p.inline_stats) DSC_LAUNCH(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
     if (p.x2) { p.x = p.cat; p.x2 = nullptr; }                  // the statistics pass wrote the concatenation: apply streams it
     DSC_LAUNCH(gn_nhwc_apply, dim3(B * p.anchunk), block, 0, st, p);

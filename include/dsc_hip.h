@@ -204,8 +204,9 @@ int dsc_groupnorm_silu(const void* x, void* y, const void* gamma, const void* be
  * Every access is a coalesced 16-byte vector; two launches (per-chunk partial sums, apply); bit-reproducible.
  */
 size_t dsc_groupnorm_nhwc_workspace_bytes(int B, int C, int hw, int groups);
-/* diagnostics: 0 = choose the kernel from the shape, 2 = always stats / finalize / apply, 3 = also allow the
- * 1024-thread single-launch kernel (measured slower than three launches; kept for tools/mb_gn.py) */
+/* diagnostics: 0 = choose the kernel from the shape, 2 = never a single-launch kernel (statistics + apply), 3 = also allow the
+ * 1024-thread single-launch kernel (measured slower; kept for tools/mb_gn.py), 4 = 2 in the old three-launch form (fine row
+ * chunks, separate finalize launch); 10 / 11 = statistics workgroups without / with channel slabs (default 11) */
 void dsc_debug_set_gn_mode(int mode);
 int dsc_groupnorm_silu_nhwc(const void* x, void* y, const void* gamma, const void* beta,
                             const void* add, int64_t add_row_stride,   /* elements between rows of `add` (>= C) */

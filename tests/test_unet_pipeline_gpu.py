@@ -66,6 +66,18 @@ def test_groupnorm_silu_nhwc(ops, B, C, h, w, G, act, with_add):
     tok = xc.permute(0, 2, 3, 1).reshape(B, h * w, C)            # token-major view gives the same bytes
     y2 = ops.groupnorm_silu_nhwc(tok, G, gamma.cuda(), beta.cuda(), 1e-5, act, add=add.cuda() if with_add else None)
     assert torch.equal(y2.reshape(B, h, w, C).permute(0, 3, 1, 2), y)
+    # the other launch forms of the two-pass kernels (no channel slabs; fine row chunks + finalize launch): same numbers up to
+    # the grouping of the fp32 / fp64 partial sums
+    from diffusionspatialcontrol_amd import _lib
+    lib = _lib.load_library()
+    try:
+        for mode in (10, 4):
+            lib.dsc_debug_set_gn_mode(mode)
+            ym = ops.groupnorm_silu_nhwc(xc, G, gamma.cuda(), beta.cuda(), 1e-5, act, add=add.cuda() if with_add else None)
+            assert (ym.float() - y.float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item()), mode
+    finally:
+        lib.dsc_debug_set_gn_mode(11)
+        lib.dsc_debug_set_gn_mode(0)
 
 
 @pytest.mark.parametrize("B,C1,C2,h,w,G,act", [(2, 1280, 1280, 8, 8, 32, True),      # single-launch kernel
