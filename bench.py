@@ -294,7 +294,15 @@ def launch_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.call(cmd, env=env)
+    # stdout of this command is ONE JSON line: whatever else the ranks' libraries print there (gloo's connection notes) goes to
+    # stderr with the rest of the log
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{") and line.rstrip().endswith("}"):
+            print(line, end="", flush=True)
+        else:
+            print(line, end="", file=sys.stderr, flush=True)
+    return proc.wait()
 
 
 def main():
