@@ -35,9 +35,10 @@ namespace {
 
 constexpr int BN = 64, BK = 64, T = 256;
 constexpr int kBHalves = BN * BK;
-constexpr int a_halves(int bm) { return bm * BK; }           // one stage: A tile (BM tokens) then B tile
-constexpr int stage_halves(int bm) { return bm * BK + kBHalves; }   // BM = 128: 12288 halves = 24 KiB; BM = 64: 16 KiB
-constexpr int kEpiStride = BN + 4;                           // fp32 staging row stride: 68 dwords -> b128 writes conflict-free
+constexpr int a_halves(int bm) { return bm * BK; }           // one stage: A tile (BM tokens) then B tile (64 NT weight rows)
+constexpr int stage_halves(int bm, int nt = 1) { return bm * BK + nt * kBHalves; }   // BM = 128: 24 KiB (NT = 2: 32 KiB); BM = 64: 16 KiB
+constexpr int epi_stride(int nt = 1) { return nt * BN + 4; } // fp32 staging row stride: 68 (132) dwords -> b128 writes conflict-free
+constexpr int kEpiStride = epi_stride(1);
 
 struct GemmParams {
     const half_t* x; const half_t* w; const half_t* bias; const half_t* res; half_t* out;
@@ -95,24 +96,30 @@ __device__ __forceinline__ void row_stats(const GemmParams& p, long long m, floa
 // NLOAD > 0: NLOAD extra waves do nothing but the tiles' LDS-DMA (an LDS-DMA instruction costs the issuing wave 100-200 cycles
 // of issue time - 6 per K tile beside 8 MFMAs of 32 cycles in the plain kernel); the four computing waves then only read LDS
 // and issue MFMAs between the per-tile barriers, which all waves join.
-template <bool GEGLU, int STAGES, int BM, int NLOAD>
+//
+// NT = 2: the workgroup's tile is 128 output columns wide (wave tile 64 x 64: one LDS fragment read per MFMA instead of 1.5,
+// and a third less L2 -> LDS traffic per output than two 128 x 64 tiles - the many-workgroup GEMMs are bound by exactly that).
+template <bool GEGLU, int STAGES, int BM, int NLOAD, int NT = 1>
 __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))) void gemm_tn_f16(GemmParams p) {
     static_assert(BM == 128 || (BM == 64 && !GEGLU), "tile heights");
+    static_assert(NT == 1 || (NT == 2 && BM == 128 && NLOAD == 0), "tile widths");
     constexpr bool LOADER = NLOAD > 0;
     constexpr int NISS = LOADER ? NLOAD : 4;                 // waves that issue DMA
     constexpr int MT = BM / 64;                              // 32-row fragments per wave
-    constexpr int kAHalves = a_halves(BM), kStage = stage_halves(BM);
-    constexpr int kPieces = (BM / 8 + 8) / NISS;             // DMA instructions per issuing wave and K tile
+    constexpr int BNT = BN * NT;                             // weight rows per tile (GEGLU: half hidden, half gate)
+    constexpr int kAHalves = a_halves(BM), kStage = stage_halves(BM, NT);
+    constexpr int kPieces = (BM / 8 + BNT / 8) / NISS;       // DMA instructions per issuing wave and K tile
+    constexpr int kES = epi_stride(NT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* lds = reinterpret_cast<half_t*>(smem);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): (BM/2) x 32 per wave
-    const int nb = GEGLU ? p.N / 64 : p.N / BN;              // column blocks (GEGLU: 32 output columns per block)
+    const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): (BM/2) x 32 NT per wave
+    const int nb = p.N / BNT;                                // column blocks (GEGLU: 32 NT output columns per block)
     const int bid = blockIdx.x;
     const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel (L2)
     const int m0 = bm * BM;
-    const int n0 = GEGLU ? bn * 32 : bn * BN;
+    const int n0 = GEGLU ? bn * (32 * NT) : bn * BNT;
     const int Nh = p.N / 2;
 
     const int iw = LOADER ? wave - 4 : wave;                 // index among the issuing waves
@@ -120,28 +127,30 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         half_t* a = lds + buf * kStage;
         dma_tile<BM, NISS>(p.x, p.ldx, m0, p.M, kt * BK, a, iw, lane);
         if (GEGLU) {
-            // B tile rows 0..31 = w[n0 .. n0+32), rows 32..63 = w[Nh + n0 .. Nh + n0 + 32): two half-tiles of 4 pieces
+            // B tile rows 0..32NT-1 = w[n0 ..), rows 32NT.. = w[Nh + n0 ..): two half-tiles
             half_t* b = a + kAHalves;
 #pragma unroll
-            for (int pc = 0; pc < 8 / NISS; ++pc) {
-                const int piece = pc * NISS + iw;            // 8 pieces of 8 rows
+            for (int pc = 0; pc < BNT / 8 / NISS; ++pc) {
+                const int piece = pc * NISS + iw;            // pieces of 8 rows
                 const int row = piece * 8 + (lane >> 3);
-                const int grow = (row < 32 ? n0 + row : Nh + n0 + row - 32);
+                const int grow = (row < 32 * NT ? n0 + row : Nh + n0 + row - 32 * NT);
                 const int chunk = (lane & 7) ^ ((row >> 1) & 7);
                 const half_t* src = p.w + (long long)grow * p.K + kt * BK + chunk * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(b + piece * 512), 16, 0, 0);
             }
         } else {
-            dma_tile<BN, NISS>(p.w, p.K, n0, p.N, kt * BK, a + kAHalves, iw, lane);
+            dma_tile<BNT, NISS>(p.w, p.K, n0, p.N, kt * BK, a + kAHalves, iw, lane);
         }
     };
 
-    f16x_t acc[MT];
+    f16x_t acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
     const int nk = p.K / BK;
     // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (kPieces DMA instructions each) are outstanding
@@ -177,7 +186,8 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     if (p.ln_in && threadIdx.x < BM && m0 + (int)threadIdx.x < p.M) row_stats(p, m0 + threadIdx.x, ln_mu, ln_rs);
     // column constants of this thread's epilogue chunks (its chunk column is the same in every pass): bias and, for a folded
     // LayerNorm, the weight-row sums - fetched here so that their latency rides under the K loop, not in the epilogue
-    const int ech = GEGLU ? (threadIdx.x & 3) : (threadIdx.x & 7);
+    constexpr int CR = (GEGLU ? 4 : 8) * NT;                 // 8-column output chunks per tile row
+    const int ech = threadIdx.x % CR;
     h8_t bpre0 = {0, 0, 0, 0, 0, 0, 0, 0}, bpre1 = {0, 0, 0, 0, 0, 0, 0, 0};
     f4x_t cpre[GEGLU ? 4 : 2];
 #pragma unroll
@@ -205,22 +215,25 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         const half_t* b = a + kAHalves;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            const h8_t wf = lds_frag(b, wn * 32 + r, 2 * ks + hh);                    // W[n][16 ks + 8 hh ..]
+            h8_t wf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag(b, wn * (32 * NT) + nt * 32 + r, 2 * ks + hh);   // W[n][16 ks + 8 hh ..]
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const h8_t xf = lds_frag(a, wm * (BM / 2) + mt * 32 + r, 2 * ks + hh);   // X[m][...]
-                acc[mt] = mfma_32x32x16(wf, xf, acc[mt]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_32x32x16(wf[nt], xf, acc[mt][nt]);
             }
         }
     }
     // residual rows of this thread's four output chunks: issued before the staging pass so that their latency (HBM /
     // Infinity Cache: the residual stream was written by an earlier kernel) hides under it
-    constexpr int NCH = BM / 32;                             // output chunks per thread (plain epilogue): 4 or 2
+    constexpr int NCH = BM * CR / T;                         // output chunks per thread: 4 or 2 (8 / 4 with NT = 2)
     h8_t rpre[NCH];
     if (!GEGLU) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
+            const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
             rpre[c] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
             if (p.res && m0 + row < p.M) rpre[c] = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
         }
@@ -232,22 +245,24 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f4x_t v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-            *reinterpret_cast<f4x_t*>(stage + (wm * (BM / 2) + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = v;
-        }
-    float* rowst = stage + BM * kEpiStride;                  // [BM][2] (mu, rstd) of the folded LayerNorm, behind the stage
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4x_t v = {acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1], acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]};
+                *reinterpret_cast<f4x_t*>(stage + (wm * (BM / 2) + mt * 32 + r) * kES + wn * (32 * NT) + nt * 32 + 8 * g + 4 * hh) = v;
+            }
+    float* rowst = stage + BM * kES;                         // [BM][2] (mu, rstd) of the folded LayerNorm, behind the stage
     if (p.ln_in && threadIdx.x < BM) { rowst[2 * threadIdx.x] = ln_mu; rowst[2 * threadIdx.x + 1] = ln_rs; }
     __syncthreads();
     if (GEGLU) {
-        // output tile 128 x 32: 4 chunks of 8 columns per row -> 512 chunks, 2 per thread
+        // output tile 128 x 32 NT: CR chunks of 8 columns per row, NCH per thread
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int idx = threadIdx.x + c * T, row = idx >> 2, ch = idx & 3;
+        for (int c = 0; c < NCH; ++c) {
+            const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
             float mu = 0.f, rs = 1.f;
             if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
             if (m0 + row < p.M) {
-                const float* sp = stage + row * kEpiStride + ch * 8;
+                const float* sp = stage + row * kES + ch * 8;
                 const h8_t bh = bpre0, bg = bpre1;                 // ch == ech: T is a multiple of the chunks per row
                 h8_t o;
                 float ch_[8], cg_[8];
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                 for (int j = 0; j < 4; ++j) { ch_[j] = cpre[0][j]; ch_[4 + j] = cpre[1][j]; cg_[j] = cpre[GEGLU ? 2 : 0][j]; cg_[4 + j] = cpre[GEGLU ? 3 : 1][j]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float ah = sp[j], ag = sp[32 + j];
+                    float ah = sp[j], ag = sp[32 * NT + j];
                     if (p.ln_in) {
                         ah = rs * (ah - mu * ch_[j]);
                         ag = rs * (ag - mu * cg_[j]);
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         }
     } else {
         // output tile BM x 64: 8 chunks per row -> 1024 (512) chunks, 4 (2) per thread; a row's 8 chunks = one 128-B segment
-        const bool scat = p.kv != nullptr && n0 >= p.kv_C;       // workgroup-uniform (C is a multiple of the 64-column block)
+        const bool scat = p.kv != nullptr && n0 + ech * 8 >= p.kv_C;   // per chunk column (uniform over a 64-column block)
         long long kv_col = 0;
         int kv_b0 = 0, kv_l0 = 0;
         if (scat) {                                               // this thread's chunk column -> (k | v, head, channel)
@@ -284,12 +299,12 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int idx = threadIdx.x + c * T, row = idx >> 3, ch = idx & 7;
-            const bool live = m0 + row < p.M;                    // a row's 8 chunks sit in 8 consecutive lanes
+            const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
+            const bool live = m0 + row < p.M;                    // a row's 8 chunks of one 64-column block sit in 8 consecutive lanes
             float s1 = 0.f, s2 = 0.f, mu = 0.f, rs = 1.f;
             if (p.ln_in) { mu = rowst[2 * row]; rs = rowst[2 * row + 1]; }
             if (live) {
-                const float* sp = stage + row * kEpiStride + ch * 8;
+                const float* sp = stage + row * kES + ch * 8;
                 const h8_t bv = bpre0, rv = rpre[c];               // ch == ech
                 h8_t o;
                 float cv_[8];
@@ -314,8 +329,8 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             if (p.ln_out) {                                       // wave-uniform
 #pragma unroll
                 for (int o2 = 1; o2 < 8; o2 <<= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
-                if (live && ch == 0) {
-                    float* dst = p.ln_out + ((long long)(m0 + row) * nb + bn) * 2;
+                if (live && (ch & 7) == 0) {
+                    float* dst = p.ln_out + ((long long)(m0 + row) * (nb * NT) + bn * NT + (ch >> 3)) * 2;
                     dst[0] = s1; dst[1] = s2;
                 }
             }
@@ -327,7 +342,8 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
 int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
-int g_gemm_loaders = 0;          // ... (stages / 10000): 0 = default (loader waves for the 64-row tiles), 4 = for every tile, 9 = never
+int g_gemm_loaders = 0;          // ... (stages / 10000 % 10): 0 = default (loader waves for the 64-row tiles), 4 = for every tile, 9 = never
+int g_gemm_nt = 0;               // ... (stages / 100000): 0 = default (128-column tiles for the GEGLU GEMMs), 1 = never, 2 = wherever N allows
 
 }  // namespace
 
@@ -336,7 +352,9 @@ extern "C" void dsc_debug_set_gemm_stages(int stages) {
     const int bm = (stages / 10) % 1000, st = stages % 10;
     g_gemm_stages = (st == 2 || st == 3) ? st : 0;
     g_gemm_bm = (bm == 64 || bm == 128) ? bm : 0;
-    g_gemm_loaders = (stages / 10000 == 4 || stages / 10000 == 9) ? stages / 10000 : 0;
+    const int ld = stages / 10000 % 10, nt = stages / 100000;
+    g_gemm_loaders = (ld == 4 || ld == 9) ? ld : 0;
+    g_gemm_nt = (nt == 1 || nt == 2) ? nt : 0;
 }
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -406,13 +424,14 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
                              reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0>),
                              reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64, 0>),
                              reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128, 4>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128, 4>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4>)};
+                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4>),
+                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128, 0, 2>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0, 2>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     // Tile height: 64 token rows when 128-row tiles would leave the chip half empty (fewer than 192 workgroups - the 16x16
     // level's C->C GEMMs: M = 512, N = 1280 -> 80 workgroups walking 20 K tiles each) and the rows allow it; GEGLU keeps 128.
-    const int nb = geglu ? N / 64 : N / BN;
+    int nb = N / BN;
     int bm = 128;
     // (measured, tools/mb_gemm.py: M=512 N=1280 K=1280 11.8 -> 8.1 us, M=8192 N=320 K=320 9.1 -> 7.5, M=8192 N=320 K=1280 24.4 ->
     // 20.7; at 480+ workgroups of 128 rows the taller tile wins: M=2048 N=1920 K=640 12.3 vs 13.5)
@@ -437,6 +456,20 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // (5- and 8-stage rings for the 64-row tiles of the small grids, in the step: M=512 N=1280 K=1280 10.8 -> 11.0 / 11.2 us,
     // M=2048 N=640 K=640 9.0 -> 9.9: the K loop is bound by what one CU ingests from L2, not by DMA latency, cold weights or not)
     const int stages = g_gemm_stages ? g_gemm_stages : ((K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3);
+    // 128-column tiles (two stages of 32 KiB, two workgroups per CU) where the grid still gives every CU a workgroup: the
+    // GEGLU GEMMs (N/2 = 1280 / 2560 / 5120 -> 1280 / 640 / 320 workgroups)
+    const bool wide_ok = bm == 128 && N % 128 == 0 && (!geglu || (N / 2) % 64 == 0) && (g_gemm_stages == 0 || g_gemm_stages == 2) && g_gemm_loaders != 4;
+    const bool wide = wide_ok && (g_gemm_nt == 2 || (g_gemm_nt == 0 && geglu && (long long)mb * (N / 128) >= 256));
+    if (wide) {
+        nb = N / 128;
+        size_t wl = (size_t)2 * stage_halves(128, 2) * sizeof(half_t);
+        const size_t we = (size_t)128 * epi_stride(2) * sizeof(float) + (size_t)128 * 2 * sizeof(float);
+        if (wl < we) wl = we;
+        const dim3 wgrid(mb * nb);
+        if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2, 128, 0, 2>), wgrid, block, wl, st, p);
+        else DSC_LAUNCH((gemm_tn_f16<false, 2, 128, 0, 2>), wgrid, block, wl, st, p);
+        return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+    }
     // the fp32 epilogue stage (bm x 68 floats + the row statistics) reuses the ring
     size_t lds = (size_t)stages * stage_halves(bm) * sizeof(half_t);
     const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float);

@@ -317,7 +317,8 @@ def test_linear_kernel_tilings_agree_bit_for_bit(ops, M, N, K, geglu):
     outs = {}
     try:
         assert ops.linear_kernel_covers(M, N, K, torch.float16, geglu=geglu)
-        for knob in (0, 90003, 40003, 90002, 91283, 41283) + (() if geglu else (90643, 40643, 90642)):
+        # 1xxxxx: never the 128-column tile, 2xxxxx: wherever N is a multiple of 128 (GEGLU: the default where the grid allows)
+        for knob in (0, 90003, 40003, 90002, 91283, 41283, 100000, 200000, 291282) + (() if geglu else (90643, 40643, 90642)):
             lib.dsc_debug_set_gemm_stages(knob)
             outs[knob] = ops.linear(x, w, b, geglu=True) if geglu else ops.linear(x, w, b, residual=r)
     finally:
@@ -458,7 +459,7 @@ def test_linear_library_bias_residual(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,C,N,geglu", [(8192, 320, 960, False), (2048, 640, 640, False), (8192, 320, 2560, True),
-                                          (1100, 64, 128, False)])
+                                          (1100, 64, 128, False), (2048, 640, 5120, True), (512, 1280, 3840, False)])
 def test_linear_layernorm_folding(ops, M, C, N, geglu):
     """dsc_linear_ln_f16: producer GEMM emits row statistics, consumer GEMM applies the folded LayerNorm
     == add + LayerNorm + linear of the three-launch path"""
@@ -493,10 +494,21 @@ def test_linear_layernorm_folding(ops, M, C, N, geglu):
     y0 = ops.linear(hk, w, b, geglu=geglu)
     assert (y.float() - y0.float()).abs().mean().item() < 2e-3
     assert torch.equal(y, ops.linear_ln(s, w2, b2, geglu=geglu, ln=(st, cvec, 1e-5)))
+    # the 128-column tile: statistics per 64-column block and folded-LayerNorm epilogue give the same bytes
+    from diffusionspatialcontrol_amd import _lib
+    lib = _lib.load_library()
+    try:
+        for knob in (100000, 200000):
+            lib.dsc_debug_set_gemm_stages(knob)
+            s_k, st_k = ops.linear_ln(a, wo, bo, residual=x, ln_stats=True)
+            assert torch.equal(s_k, s) and torch.equal(st_k, st), knob
+            assert torch.equal(ops.linear_ln(s, w2, b2, geglu=geglu, ln=(st, cvec, 1e-5)), y), knob
+    finally:
+        lib.dsc_debug_set_gemm_stages(0)
 
 
 @pytest.mark.parametrize("B,L,C,H,fold", [(2, 4096, 320, 8, True), (2, 1024, 640, 8, False), (3, 576, 320, 8, True), (16, 64, 320, 5, False),
-                                         (1, 9216, 320, 8, False)])
+                                         (1, 9216, 320, 8, False), (2, 1024, 640, 8, True), (2, 256, 1280, 8, True)])
 def test_linear_qkv_head_major(ops, B, L, C, H, fold):
     """dsc_linear_qkv_f16: the fused q / k / v projection whose epilogue writes K and V head-major ([2, B, H, L, d]) equals
     the plain fused projection bit for bit (same GEMM, another store address), with and without a folded LayerNorm; token
@@ -522,6 +534,15 @@ def test_linear_qkv_head_major(ops, B, L, C, H, fold):
     assert q4.shape == k4.shape == v4.shape == (B, L, H, d)
     assert k4.stride() == (H * L * d, d, L * d, 1)                     # a head's keys are contiguous
     assert torch.equal(q4, rq) and torch.equal(k4, rk) and torch.equal(v4, rv)
+    if (3 * C) % 128 == 0:                  # 128-column tiles: a tile may hold query AND key columns - the scatter is per chunk
+        from diffusionspatialcontrol_amd import _lib
+        lib = _lib.load_library()
+        try:
+            lib.dsc_debug_set_gemm_stages(200000)
+            qw, kw_, vw = ops.linear_qkv(x, w2, b2, H, ln=ln) if fold else ops.linear_qkv(x, w, None, H)
+        finally:
+            lib.dsc_debug_set_gemm_stages(0)
+        assert torch.equal(qw, rq) and torch.equal(kw_, rk) and torch.equal(vw, rv)
     # and the flash kernel on the head-major views equals the flash kernel on the token-major ones
     assert torch.equal(ops.self_attention(q4, k4, v4), ops.self_attention(rq, rk, rv))
 
