@@ -54,6 +54,7 @@ struct GemmParams {
     // stride ldo), columns [C, 3C) to kv[which][b][h][l][dd] - each head's keys / values contiguous, so that the flash
     // kernel's 64-key tiles are plain contiguous 1-KiB DMA pieces instead of 80-byte row segments 1920 bytes apart
     half_t* kv; int kv_C, kv_H, kv_d, kv_L, kv_B;
+    int xcd_remap, total;        // virtual workgroup order (see the kernel) and the number of real tiles
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -116,8 +117,20 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     const int r = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): (BM/2) x 32 NT per wave
     const int nb = p.N / BNT;                                // column blocks (GEGLU: 32 NT output columns per block)
-    const int bid = blockIdx.x;
-    const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel (L2)
+    // XCD-aware order (as in conv3x3.hip): workgroup i runs on XCD i % 8, so consecutive VIRTUAL ids - the column blocks of
+    // one activation panel - go to one XCD and that panel is fetched into one L2 instead of eight
+    // Each XCD has its own L2 and workgroup i runs on XCD i % 8.  xcd_remap (activation-heavy shapes, M >= 2 N): consecutive
+    // VIRTUAL ids - the column blocks of one row panel - go to one XCD, so a panel is fetched into one L2 instead of eight
+    // (in the step: M=8192 N=320 K=320 9.7 -> 8.6 us, N=960 18.8 -> 17.5).  Weight-heavy shapes keep the plain order: there it
+    // loses (M=512 N=10240 GEGLU 27.0 -> 34.2 us), and so does the mirrored order - one XCD walking all row panels of a few
+    // column blocks, an eighth of the weights per L2 - (29.1 -> 33.7).
+    int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        const int per = gridDim.x >> 3;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= p.total) return;                          // grid padded to a multiple of 8 (before any barrier)
+    }
+    const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel
     const int m0 = bm * BM;
     const int n0 = GEGLU ? bn * (32 * NT) : bn * BNT;
     const int Nh = p.N / 2;
@@ -343,6 +356,7 @@ bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
 int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
 int g_gemm_loaders = 0;          // ... (stages / 10000 % 10): 0 = default (loader waves for the 64-row tiles), 4 = for every tile, 9 = never
+int g_gemm_xcd = 0;              // ... (stages / 1000000): 0 = by shape, 1 = plain blockIdx order, 2 = the XCD-aware order everywhere
 int g_gemm_nt = 0;               // ... (stages / 100000): 0 = default (128-column tiles for the GEGLU GEMMs), 1 = never, 2 = wherever N allows
 
 }  // namespace
@@ -352,7 +366,8 @@ extern "C" void dsc_debug_set_gemm_stages(int stages) {
     const int bm = (stages / 10) % 1000, st = stages % 10;
     g_gemm_stages = (st == 2 || st == 3) ? st : 0;
     g_gemm_bm = (bm == 64 || bm == 128) ? bm : 0;
-    const int ld = stages / 10000 % 10, nt = stages / 100000;
+    const int ld = stages / 10000 % 10, nt = stages / 100000 % 10;
+    g_gemm_xcd = stages / 1000000 <= 2 ? stages / 1000000 : 0;
     g_gemm_loaders = (ld == 4 || ld == 9) ? ld : 0;
     g_gemm_nt = (nt == 1 || nt == 2) ? nt : 0;
 }
@@ -442,7 +457,9 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // costs ~1000 cycles because a CU ingests only ~24 B/cycle from L2 (24 KiB per tile), not because of DMA latency -
     // the kernel is L2->LDS bandwidth bound at this tile size (43 FLOP per staged byte), which caps it near 25 % of the
     // MFMA peak; the dispatch in ops.linear therefore sends long-K shapes to hipBLASLt's larger macro-tiles.
-    const dim3 grid(mb * nb), block(T);
+    p.xcd_remap = g_gemm_xcd == 0 ? (M >= 2ll * N ? 1 : 0) : (g_gemm_xcd == 2 ? 1 : 0);
+    p.total = mb * nb;
+    const dim3 grid(p.xcd_remap ? ((mb * nb + 7) / 8) * 8 : mb * nb), block(T);
     // Two stages (48 KiB: three workgroups per CU instead of two) for grids of many workgroups per CU: with K = 320 / 640 the
     // K loop is a third of a workgroup's time (prologue DMA chain, LayerNorm / GEGLU epilogue), and a third co-resident
     // workgroup overlaps those parts (tools/mb_gemm.py)
@@ -462,10 +479,11 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     const bool wide = wide_ok && (g_gemm_nt == 2 || (g_gemm_nt == 0 && geglu && (long long)mb * (N / 128) >= 256));
     if (wide) {
         nb = N / 128;
+        p.total = mb * nb;
         size_t wl = (size_t)2 * stage_halves(128, 2) * sizeof(half_t);
         const size_t we = (size_t)128 * epi_stride(2) * sizeof(float) + (size_t)128 * 2 * sizeof(float);
         if (wl < we) wl = we;
-        const dim3 wgrid(mb * nb);
+        const dim3 wgrid(p.xcd_remap ? ((mb * nb + 7) / 8) * 8 : mb * nb);
         if (geglu) DSC_LAUNCH((gemm_tn_f16<true, 2, 128, 0, 2>), wgrid, block, wl, st, p);
         else DSC_LAUNCH((gemm_tn_f16<false, 2, 128, 0, 2>), wgrid, block, wl, st, p);
         return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;

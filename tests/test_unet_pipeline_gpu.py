@@ -318,7 +318,8 @@ def test_linear_kernel_tilings_agree_bit_for_bit(ops, M, N, K, geglu):
     try:
         assert ops.linear_kernel_covers(M, N, K, torch.float16, geglu=geglu)
         # 1xxxxx: never the 128-column tile, 2xxxxx: wherever N is a multiple of 128 (GEGLU: the default where the grid allows)
-        for knob in (0, 90003, 40003, 90002, 91283, 41283, 100000, 200000, 291282) + (() if geglu else (90643, 40643, 90642)):
+        # [12]xxxxxx: workgroup order plain / XCD-aware
+        for knob in (0, 90003, 40003, 90002, 91283, 41283, 100000, 200000, 291282, 1000000, 2000000, 2200000) + (() if geglu else (90643, 40643, 90642)):
             lib.dsc_debug_set_gemm_stages(knob)
             outs[knob] = ops.linear(x, w, b, geglu=True) if geglu else ops.linear(x, w, b, residual=r)
     finally:
