@@ -52,6 +52,7 @@ struct ConvParams {
     long long onpix;              // output pixels (npix, or npix / 4 with sub2)
     long long ldx, ldr, ldo;      // pixel strides (elements)
     int nc, splits, cps;          // 64-channel slices, split count, slices per split
+    int order;                    // workgroup order within an XCD (see the kernel)
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
     int mt, nt;                   // tiles along pixels / output channels
     long long npix;
@@ -139,9 +140,16 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
     if (v >= total) return;
     long long st0 = 0, st1 = 0, st2 = 0, sc0 = 0, sc1 = 0, sc2 = 0;
     if (p.stamps) { st0 = __builtin_amdgcn_s_memrealtime(); sc0 = __builtin_amdgcn_s_memtime(); }
-    const int bm = v % p.mt;
-    const int rest = v / p.mt;
-    const int bn = rest % p.nt, sp = rest / p.nt;
+    int bm, bn, sp;
+    if (p.order) {                                           // channel blocks fastest: one XCD shares a pixel tile's halo
+        bn = v % p.nt;
+        const int rest = v / p.nt;
+        bm = rest % p.mt; sp = rest / p.mt;
+    } else {                                                 // pixel tiles fastest: one XCD shares a weight slab
+        bm = v % p.mt;
+        const int rest = v / p.mt;
+        bn = rest % p.nt; sp = rest / p.nt;
+    }
     const int n0 = bn * BN;
     const int cb = sp * p.cps, ce = min(p.nc, cb + p.cps);
     const int ns = (ce - cb) * 9;
@@ -431,6 +439,7 @@ int tile_width(int H, int W) {
 //   fixed     5 (launch, prologue, epilogue)
 //   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
 // e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
+int g_conv_order = -1;             // dsc_debug_set_conv_ring(300 / 301): pixel tiles / channel blocks fastest within an XCD (-1: by shape)
 double g_conv_small_step = 0.26;   // us per step of a grid of <= 256 workgroups (dsc_debug_set_conv_ring(200 + hundredths))
 int auto_splits(int tiles, int nc, long long npix, int cout) {
     int best = 1;
@@ -469,7 +478,8 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
 extern "C" void dsc_debug_set_conv_ring(int stages) {
-    if (stages >= 200) g_conv_small_step = (stages - 200) / 100.0;
+    if (stages >= 300) g_conv_order = stages - 300;
+    else if (stages >= 200) g_conv_small_step = (stages - 200) / 100.0;
     else g_conv_ring = stages;
 }
 
@@ -505,6 +515,9 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     p.out = static_cast<half_t*>(out); p.ws = static_cast<float*>(workspace);
     p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.stamps = g_conv_stamps;
+    // activation-heavy shapes (the 64x64 level): a pixel tile's halo is fetched into one L2 for all of its channel blocks
+    // (640->320 @64x64 66.8 -> 61.5 us in the step); weight-heavy ones keep sharing the weight slab
+    p.order = g_conv_order >= 0 ? g_conv_order : (p.npix >= 2ll * Cout ? 1 : 0);
     if (resample < 0 || resample > 3 || ((resample == DSC_CONV_STRIDE2 || resample == DSC_CONV_STRIDE2_PAD_BR) && out_nchw)) return DSC_ERR_UNSUPPORTED;
     if ((resample == DSC_CONV_STRIDE2 || resample == DSC_CONV_STRIDE2_PAD_BR) && ((H | W) & 1)) return DSC_ERR_UNSUPPORTED;
     p.up = resample == DSC_CONV_UPSAMPLE2X ? 1 : 0;
