@@ -82,11 +82,22 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
             else { base = p.x2 + (long long)b * p.HW * c2 + (c8 * 8 - p.C1); rs = c2; }
             cdst = p.cat + (long long)b * p.HW * p.C + c8 * 8;
         }
-        for (int row = r0 + slice; row < r1; row += p.sk) {
-            const h8_t v = *reinterpret_cast<const h8_t*>(base + (long long)row * rs);
-            if (cdst) *reinterpret_cast<h8_t*>(cdst + (long long)row * p.C) = v;
+        // four rows in flight per thread (the loads of a runtime-bounded loop are otherwise issued one latency apart)
+        for (int row = r0 + slice; row < r1; row += 4 * p.sk) {
+            h8_t v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j] + ad[j]; s[j] += f; q[j] += f * f; }
+            for (int u = 0; u < 4; ++u) {
+                v[u] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (row + u * p.sk < r1) v[u] = *reinterpret_cast<const h8_t*>(base + (long long)(row + u * p.sk) * rs);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (row + u * p.sk < r1) {
+                    if (cdst) *reinterpret_cast<h8_t*>(cdst + (long long)(row + u * p.sk) * p.C) = v[u];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j] + ad[j]; s[j] += f; q[j] += f * f; }
+                }
+            }
         }
     }
 #pragma unroll
@@ -138,11 +149,29 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     __shared__ float mean_s[64], rstd_s[64];
     __shared__ double red[8 * 64 * 2];
     const int b = blockIdx.x / p.anchunk, chunk = blockIdx.x % p.anchunk;
-    // this thread's first rows go out before the statistics are read: their latency hides the (mean, rstd) fetch and fold
-    constexpr int kPre = 4;
+    // Every load this workgroup's first rows need is issued up front, in the order the values are needed (a wave's loads
+    // return in order): the statistics partials, the channel constants, then the first rows - so the partial sums are being
+    // added while the rows are still in flight, and nothing is fetched behind a barrier.
+    constexpr int kPre = 4, kPL = 5;                          // rows / partial rows per thread in flight
     const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
     const int r0 = chunk * p.arows, r1 = min(r0 + p.arows, p.HW);
     const long long off = (long long)b * p.HW * p.C + c8 * 8;
+    // few statistics chunks (<= 32 per image): every apply workgroup adds them itself, in a fixed order - 16 KB of
+    // L2 reads instead of a third launch.  thread (g, part): chunks part, part + P, ...; then the P parts in order
+    const int P = min(8, (int)blockDim.x / p.G);
+    const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+    const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
+    double pl1[kPL], pl2[kPL];
+#pragma unroll
+    for (int u = 0; u < kPL; ++u) {
+        const int i = part + u * P;
+        pl1[u] = 0.0; pl2[u] = 0.0;
+        if (p.inline_stats && part < P && i < p.nchunk) { pl1[u] = src[(long long)i * p.G * 2]; pl2[u] = src[(long long)i * p.G * 2 + 1]; }
+    }
+    const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + c8 * 8);
+    const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + c8 * 8);
+    h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
     h8_t pre[kPre];
 #pragma unroll
     for (int i = 0; i < kPre; ++i) {
@@ -151,14 +180,11 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
         if (row < r1) pre[i] = *reinterpret_cast<const h8_t*>(p.x + off + (long long)row * p.C);
     }
     if (p.inline_stats) {
-        // few statistics chunks (<= 32 per image): every apply workgroup adds them itself, in a fixed order - 16 KB of
-        // L2 reads instead of a third launch.  thread (g, part): chunks part, part + P, ...; then the P parts in order
-        const int P = min(8, (int)blockDim.x / p.G);
-        const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
         if (part < P) {
-            const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
             double a1 = 0.0, a2 = 0.0;
-            for (int i = part; i < p.nchunk; i += P) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+#pragma unroll
+            for (int u = 0; u < kPL; ++u) { a1 += pl1[u]; a2 += pl2[u]; }         // (missing chunks add zero)
+            for (int i = part + kPL * P; i < p.nchunk; i += P) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
             red[(part * 64 + g) * 2] = a1; red[(part * 64 + g) * 2 + 1] = a2;
         }
         __syncthreads();
@@ -179,15 +205,11 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     __syncthreads();
     float sc[8], sh[8];
     {
-        const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + c8 * 8);
-        const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + c8 * 8);
-        h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + c8 * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int g = (c8 * 8 + j) / p.cpg;
-            sc[j] = (float)ga[j] * rstd_s[g];
-            sh[j] = (float)be[j] + ((float)ad[j] - mean_s[g]) * sc[j];
+            const int gg = (c8 * 8 + j) / p.cpg;
+            sc[j] = (float)ga[j] * rstd_s[gg];
+            sh[j] = (float)be[j] + ((float)ad[j] - mean_s[gg]) * sc[j];
         }
     }
     auto emit = [&](int row, const h8_t& v) {
@@ -220,6 +242,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
     const int nvec = p.HW * vpp;
     const long long base = (long long)b * p.HW * p.C + g * p.cpg;
     float v[kSmallVec][8];
+    h8_t gav[kSmallVec], bev[kSmallVec];
     float s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < kSmallVec; ++i) {
@@ -229,9 +252,14 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
             const h8_t x = gn_load(p, b, pix, g * p.cpg + j8 * 8);
             h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
             if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + g * p.cpg + j8 * 8);
+            // the channel constants ride along now: fetched after the second reduction they were a memory round trip of
+            // their own at the end of a kernel that is nothing but a latency chain
+            gav[i] = *reinterpret_cast<const h8_t*>(p.gamma + g * p.cpg + j8 * 8);
+            bev[i] = *reinterpret_cast<const h8_t*>(p.beta + g * p.cpg + j8 * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[i][j] = (float)x[j] + (float)ad[j]; s1 += v[i][j]; }
         } else {
+            gav[i] = h8_t{0, 0, 0, 0, 0, 0, 0, 0}; bev[i] = gav[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
@@ -260,8 +288,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
         const int idx = threadIdx.x + 256 * i;
         if (idx < nvec) {
             const int pix = idx / vpp, j8 = idx - pix * vpp;
-            const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + g * p.cpg + j8 * 8);
-            const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + g * p.cpg + j8 * 8);
+            const h8_t ga = gav[i], be = bev[i];
             h8_t o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
