@@ -347,7 +347,7 @@ DSC_GEMM_MAX_K = int(os.environ.get("DSC_GEMM_MAX_K", "640"))       # kernels fo
 USE_LN_FOLD = os.environ.get("DSC_LN_FOLD", "1") != "0"   # BasicTransformerBlock: LayerNorms folded into the GEMMs (dsc_linear_ln_f16)
 
 
-DSC_GEMM_MID_ROWS = 512 if os.environ.get("DSC_GEMM_MID", "1") != "0" else 1 << 30    # 512 <= rows < 1024 (the 16x16 level at batch 1): the kernel up to K = 1280 - a wash per GEMM against the
+DSC_GEMM_MID_ROWS = int(os.environ.get("DSC_GEMM_MID_ROWS", "512")) if os.environ.get("DSC_GEMM_MID", "1") != "0" else 1 << 30    # 512 <= rows < 1024 (the 16x16 level at batch 1): the kernel up to K = 1280 - a wash per GEMM against the
 DSC_GEMM_MID_K = int(os.environ.get("DSC_GEMM_MID_K", "1280"))      # library (QKV 14.0 vs 15.4 us, C->C 11.8 vs 11.1), but it lets the block's three LayerNorms fold into
 #                            its GEMMs (three add+LayerNorm launches of 6.5 us fewer) and K / V leave the QKV GEMM head-major
 
