@@ -267,7 +267,9 @@ int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
 /* diagnostics: 8 x int64 per workgroup (start / loop start / loop end / end in 100 MHz ticks, the three segment lengths in
  * shader clocks, XCC and HW ids) of every following dsc_conv3x3_nhwc_f16 call go to `device_buffer`; NULL switches it off */
 void dsc_debug_set_conv_stamps(void* device_buffer);
-/* diagnostics: force the weight-tile ring depth (3 or 9 stages); 0 = chosen from the grid size */
+/* diagnostics: 3 / 9 = force the weight-tile ring depth, 0 = by grid size and tuning profile; 200 + n = the split-count
+ * model's per-step time for grids of <= 256 workgroups (n / 100 us); 300 / 301 = pixel tiles / channel blocks fastest
+ * within an XCD (default: by shape) */
 void dsc_debug_set_conv_ring(int stages);
 size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
 int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -298,8 +300,13 @@ int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void
  * row segments 3C elements apart).  Same LayerNorm-folding arguments as dsc_linear_ln_f16 (ln_in NULL = plain GEMM).
  * Needs C % 64 == 0, (C / heads) % 8 == 0, K % 64 == 0, M % seq_len == 0.
  */
-/* diagnostics: force the K-tile ring depth of dsc_linear_f16 / _ln_f16 / _qkv_f16 (v % 10: 2 or 3 stages, else the default)
- * and its tile height (v / 10: 64 or 128 token rows, else the default) - e.g. 643 = 64-row tiles, 3 stages; 0 = defaults */
+/* diagnostics: launch variant of dsc_linear_f16 / _ln_f16 / _qkv_f16, one decimal field each (0 = the measured rule):
+ *   v % 10            K-tile ring depth (2 or 3 stages)
+ *   v / 10 % 1000     tile height (64 or 128 token rows)                          e.g. 643 = 64-row tiles, 3 stages
+ *   v / 10000 % 10    DMA-only loader waves: 4 = for every tile, 9 = never
+ *   v / 100000 % 10   128-column tiles: 1 = never, 2 = wherever N is a multiple of 128
+ *   v / 1000000       workgroup order: 1 = plain blockIdx, 2 = XCD-aware for every shape
+ * Every variant gives equal bytes (tests/test_unet_pipeline_gpu.py::test_linear_kernel_tilings_agree_bit_for_bit). */
 void dsc_debug_set_gemm_stages(int stages);
 int dsc_linear_qkv_f16(const void* x, const void* w, const void* bias, void* q_out, void* kv_out,
                        int64_t M, int C, int K, int64_t ldx, int64_t ldq, int heads, int seq_len,
