@@ -327,7 +327,7 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
             const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
             const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
             long long gp = ((long long)b * p.H + yy) * p.W + xx;
-            bool live = b >= 0 && n0 + ch * 8 + 8 <= p.Cout;
+            bool live = b >= 0 && yy < p.H && xx < p.W && n0 + ch * 8 + 8 <= p.Cout;
             if (p.sub2) { live = live && (p.sub2 == 1 ? !((yy | xx) & 1) : (yy & xx & 1) != 0); gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1); }
             if (live) rpre[cidx] = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + n0 + ch * 8);
         }
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
         const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
         if (b < 0) continue;
         const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
+        if (yy >= p.H || xx >= p.W) continue;                        // overhang of a ragged image side
         long long gp = ((long long)b * p.H + yy) * p.W + xx;
         if (p.sub2) {                                                // stride 2 = the even (odd) pixels of the stride-1 result
             if (p.sub2 == 1 ? ((yy | xx) & 1) != 0 : (yy & xx & 1) == 0) continue;
@@ -427,11 +428,13 @@ int g_conv_ring = 0;          // diagnostics (dsc_debug_set_conv_ring): 0 = from
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // tile width for an image, 0 = unsupported geometry
+// Image sides need not be multiples of the tile (12 x 12: the lowest level of a 768 x 768 generation): sub-blocks hang over the
+// bottom / right edge, their halo reads beyond the image deposit zeros like the padding does, their stores are masked.
 int tile_width(int H, int W) {
-    if (H % 8 != 0) return 0;
+    if (H < 1 || W < 1) return 0;
     if (W % 16 == 0) return 16;
     if (W % 8 == 0) return 8;
-    return 0;
+    return ((W + 15) / 16 * 16 - W <= (W + 7) / 8 * 8 - W) ? 16 : 8;      // the less overhang
 }
 
 // Split count from a cost model fitted to tools/mb_conv3.py on MI355X (us):
@@ -461,7 +464,7 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
     if (!tw || Cin % BK != 0 || Cout <= 0) return 0;
     p->B = B; p->H = H; p->W = W; p->Cin = Cin; p->Cout = Cout;
     p->nc = Cin / BK;
-    p->bpr = W / tw; p->bpi = (H / 8) * p->bpr; p->nblk = B * p->bpi;
+    p->bpr = (W + tw - 1) / tw; p->bpi = ((H + 7) / 8) * p->bpr; p->nblk = B * p->bpi;
     const int nsb = 16 / tw;
     p->mt = (p->nblk + nsb - 1) / nsb; p->nt = (Cout + BN - 1) / BN;    // a ragged last tile reads zero weight rows (buffer bounds)
     p->npix = (long long)B * H * W;

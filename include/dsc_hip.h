@@ -256,8 +256,9 @@ int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* r
  * layout).  Cout need not be a multiple of 64: a ragged last channel tile reads zero weight rows through the buffer bounds.
  * splits: number of input-channel ranges accumulated by separate workgroups (0 = chosen from the shape); splits > 1
  * needs `workspace` (dsc_conv3x3_workspace_bytes) and sums the partials in range order: bit-reproducible.
- * Supported (dsc_conv3x3_supported): Cin % 64 == 0, H % 8 == 0, W % 8 == 0, strides % 8 == 0 (when Cout % 8 == 0), 16-byte
- * aligned pointers; anything else returns DSC_ERR_UNSUPPORTED and the caller keeps the library convolution.
+ * Supported (dsc_conv3x3_supported): Cin % 64 == 0, strides % 8 == 0 (when Cout % 8 == 0), 16-byte aligned pointers; any
+ * H, W >= 1 (sides that are not multiples of the 8 x 16 / 8 x 8 pixel tile - 12 x 12, the lowest level of a 768 x 768 generation -
+ * cost the overhang's MFMAs, nothing else); anything else returns DSC_ERR_UNSUPPORTED and the caller keeps the library convolution.
  */
 #define DSC_CONV_UPSAMPLE2X 1
 #define DSC_CONV_STRIDE2 2

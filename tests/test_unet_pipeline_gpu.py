@@ -218,7 +218,10 @@ def test_linear_kernel(ops, M, N, K):
     (2, 320, 320, 64, 64, 0), (2, 640, 320, 64, 64, 0), (2, 640, 640, 32, 32, 0), (2, 640, 640, 32, 32, 1),
     (2, 1920, 640, 32, 32, 0), (2, 1280, 1280, 16, 16, 0), (2, 2560, 1280, 16, 16, 0), (2, 1280, 1280, 8, 8, 0),
     (2, 2560, 1280, 8, 8, 0), (1, 64, 64, 8, 8, 0), (3, 128, 64, 8, 8, 2), (1, 64, 128, 16, 24, 0), (2, 192, 64, 24, 48, 3),
-    (1, 320, 320, 96, 96, 0), (5, 64, 64, 8, 16, 0)])
+    (1, 320, 320, 96, 96, 0), (5, 64, 64, 8, 16, 0),
+    # image sides that are not multiples of the pixel tile (the 12 x 12 level of a 768 x 768 generation)
+    (2, 1280, 1280, 12, 12, 0), (16, 1280, 1280, 12, 12, 0), (2, 128, 64, 12, 20, 2), (1, 64, 64, 5, 7, 0), (3, 64, 128, 9, 30, 0),
+    (1, 64, 64, 1, 1, 0)])
 def test_conv3x3_kernel(ops, B, Cin, Cout, H, W, splits):
     """dsc_conv3x3_nhwc_f16 vs an fp32 convolution on fp16-representable operands (one fp16 rounding of the fp32 sum):
     image borders (zero padding), 16- and 8-wide tiles, ragged last tile, split input-channel ranges, bias + residual."""
@@ -246,7 +249,7 @@ def test_conv3x3_kernel(ops, B, Cin, Cout, H, W, splits):
     # a localised impulse: every tap lands where it should (catches halo / tap-offset indexing independent of tolerance)
     xi = torch.zeros(B, Cin, H, W).half()
     xi[B - 1, 5, H - 1, 0] = 1.0
-    xi[0, Cin - 1, 3, W - 1] = 2.0
+    xi[0, Cin - 1, min(3, H - 1), W - 1] = 2.0
     oi = ops.conv3x3(xi.cuda().contiguous(memory_format=cl), wd, None, splits=splits).float().cpu()
     ri = F.conv2d(xi.float(), w.float(), None, padding=1)
     assert torch.all((oi - ri).abs() <= 1e-3 * ri.abs() + 1e-6)
@@ -283,7 +286,8 @@ def test_conv3x3_and_gemm_profiles_give_equal_bytes(ops, B, Cin, Cout, H, W):
         assert torch.equal(outs["throughput"][1], outs["latency"][1])
 
 
-@pytest.mark.parametrize("B,C,Cout,h,w", [(2, 1280, 1280, 8, 8), (2, 640, 640, 32, 32), (1, 64, 64, 4, 12), (3, 128, 64, 4, 4)])
+@pytest.mark.parametrize("B,C,Cout,h,w", [(2, 1280, 1280, 8, 8), (2, 640, 640, 32, 32), (1, 64, 64, 4, 12), (3, 128, 64, 4, 4),
+                                          (2, 1280, 1280, 12, 12), (1, 64, 64, 3, 5)])
 def test_conv3x3_upsample(ops, B, C, Cout, h, w):
     """Upsample2D: nearest 2x + conv (diffusers) == the convolution reading the small image through the upsampling map"""
     g = torch.Generator().manual_seed(B + C + h + w)
@@ -397,7 +401,8 @@ def test_conv3x3_fewcin(ops, B, Cin, Cout, H, W):
 
 
 @pytest.mark.parametrize("B,C,Cout,H,W,splits", [(2, 320, 320, 64, 64, 0), (2, 640, 640, 32, 32, 0), (2, 1280, 1280, 16, 16, 0),
-                                                 (1, 64, 64, 8, 16, 1), (3, 128, 64, 16, 8, 2)])
+                                                 (1, 64, 64, 8, 16, 1), (3, 128, 64, 16, 8, 2), (2, 1280, 1280, 12, 12, 0),
+                                                 (1, 64, 64, 6, 10, 0)])
 def test_conv3x3_stride2(ops, B, C, Cout, H, W, splits):
     """Downsample2D: the stride-2 / pad-1 convolution as the even pixels of the stride-1 taps"""
     g = torch.Generator().manual_seed(B + C + H + W)
@@ -421,7 +426,10 @@ def test_conv3x3_unsupported(ops):
         ops.conv3x3(x, w)
     x2 = torch.randn(1, 64, 12, 12).half().cuda().contiguous(memory_format=torch.channels_last)
     w2 = torch.randn(64, 64, 3, 3).half().cuda().contiguous(memory_format=torch.channels_last)
-    assert not ops.conv3x3_supported(x2, w2)
+    assert ops.conv3x3_supported(x2, w2)                                  # image sides need not be multiples of the tile
+    x3 = torch.randn(1, 64, 11, 12).half().cuda().contiguous(memory_format=torch.channels_last)
+    with pytest.raises(Exception):
+        ops.conv3x3(x3, w2, stride2=True)                                 # the stride-2 form needs even sides
 
 
 @pytest.mark.parametrize("M,N,K", [(512, 1280, 1280), (512, 1280, 5120), (128, 1280, 1280), (8192, 320, 1280), (2048, 640, 2560),
