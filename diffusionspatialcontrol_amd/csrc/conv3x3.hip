@@ -9,7 +9,8 @@
 // filter tap.  This kernel stages the (8 x TW)+halo input patch of one 64-channel slice in LDS ONCE and serves all nine
 // taps from it, so per tap only the 8 KiB weight tile crosses L2->LDS: 43 -> 97 FLOP per ingested byte.
 //
-//   tile       128 output pixels (NSB sub-blocks of 8 x TW pixels; TW = 16, or 8 for 8-wide images) x 64 output channels
+//   tile       128 output pixels (NSB sub-blocks of 8 x TW pixels; TW = 16, or 8 for 8-wide images) x 64 output channels;
+//              image sides need not be multiples of the sub-block: the overhang reads zeros and its stores are masked
 //   K loop     input-channel slices of 64 (outer) x 9 taps (inner); optional split over slices (split-K) for the
 //              low-resolution levels, partial sums in fp32 to a workspace, reduced in slice order by a second launch -
 //              bit-reproducible, unlike MIOpen's atomic split-K (`_GKGS`) solvers

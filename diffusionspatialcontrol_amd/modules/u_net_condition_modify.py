@@ -519,7 +519,7 @@ class Transformer2DModel(nn.Module):
 
 def _conv3x3(x, weight, bias=None, residual=None):
     """3x3 / pad 1 convolution (+ bias) (+ residual): dsc_conv3x3_nhwc_f16 where it covers the shape (channels-last fp16,
-    channel counts that are multiples of 64, 8-aligned image sides), otherwise the library convolution (MIOpen) with
+    input channel counts that are multiples of 64), otherwise the library convolution (MIOpen) with
     the separate fused add."""
     if ops.conv3x3_supported(x, weight):
         return ops.conv3x3(x, weight, bias, residual)
