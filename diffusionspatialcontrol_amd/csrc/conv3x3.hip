@@ -114,9 +114,15 @@ __device__ __forceinline__ h8_t lds_read(unsigned byte_addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) h8_t*>((uintptr_t)byte_addr);
 }
 
-template <int TW, int S>
-__global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams p) {
+// NLOAD = 4: four more waves that issue every DMA of the loop and nothing else (one per SIMD beside a computing wave: 2 x 245
+// registers fit the 512 of a SIMD, but only with ONE workgroup per CU - the kernel of the <= 256-workgroup grids under the
+// latency profile).  A DMA instruction holds its wave's issue port for 60-200 cycles; in the plain kernel the 2.8 of them per
+// step sit between the 8 MFMAs of the wave that also has to feed the matrix pipe.
+template <int TW, int S, int NLOAD = 0>
+__global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void conv3x3_kernel(ConvParams p) {
     static_assert(S == 3 || S == 9, "the ring depth must divide the 9 taps");
+    static_assert(NLOAD == 0 || NLOAD == 4, "loader waves mirror the four computing waves' DMA shares");
+    constexpr bool LOADER = NLOAD > 0;
     constexpr int kAOff = a_off(S), kPadOff = pad_off(S);
     constexpr int NSB = 16 / TW;                 // sub-blocks of 8 x TW pixels per tile
     constexpr int HWD = TW + 2;                  // halo row width (even)
@@ -129,7 +135,9 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_loader = LOADER && wave_all >= 4;
+    const int wave = wave_all & 3;                           // DMA share / output quadrant of this wave
     const int r = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -174,8 +182,11 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
     auto tile_soff = [&](int c, int t) { return ((unsigned)t * (unsigned)p.Cin + (unsigned)c * BK) * 2u; };
 
     // the weight tiles of steps 0..S-1 go out first: their latency overlaps the halo index arithmetic below
+    const bool dma_wave = !LOADER || is_loader;              // this wave issues DMA
+    if (dma_wave) {
 #pragma unroll
-    for (int k = 0; k < S; ++k) issue_b(tile_soff(cb, k), k);      // ns >= 9 >= S
+        for (int k = 0; k < S; ++k) issue_b(tile_soff(cb, k), k);      // ns >= 9 >= S
+    }
 
     // ---- sub-block origins (wave-uniform: at most two per tile, so the runtime divisions run once, not per lane)
     int ob[NSB], oy[NSB], ox[NSB];
@@ -253,10 +264,37 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
 
     // ---- prologue: halo of the first slice (issued after the three weight tiles: everything must land); step 0's
     // fragments in registers
+    if (dma_wave) {
 #pragma unroll
-    for (int i = 0; i < 7; ++i) issue_a(i, cb, 0);
+        for (int i = 0; i < 7; ++i) issue_a(i, cb, 0);
+    }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (LOADER) {
+        if (is_loader) {
+            // the loop's DMA with the plain kernel's cadence: per step a counted wait, the step's barrier, the step's issues
+            for (int c = cb; c < ce; ++c) {
+                const int jb = (c - cb) * 9;
+                const int cn = c + 1 < ce ? c + 1 : c;
+                const int P = (c - cb) & 1;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    wait_step<S>(t);
+                    __builtin_amdgcn_s_barrier();
+                    if (t == 0) {
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) issue_a(i, cn, P ^ 1);
+                    }
+                    const bool more = jb + t + S < ns;
+                    const int c3 = t + S >= 9 ? c + 1 : c, t3 = (t + S) % 9;
+                    issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % S);
+                }
+            }
+            __syncthreads();                                 // the epilogue's two workgroup barriers
+            __syncthreads();
+            return;
+        }
+    }
     Frags f[2];
     load_frags(f[0], 0, 0);
     if (p.stamps) { st1 = __builtin_amdgcn_s_memrealtime(); sc1 = __builtin_amdgcn_s_memtime(); }
@@ -275,15 +313,15 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
         for (int t = 0; t < 9; ++t) {
             Frags& cur = f[(P + t) & 1];
             Frags& nxt = f[(P + t + 1) & 1];
-            wait_step<S>(t);
+            if (!LOADER) wait_step<S>(t);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // step j's fragments are in registers
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);                       // keep step j+1's MFMAs out of step j (they would wait on their reads)
-            if (t == 0) {
+            if (!LOADER) {
+                if (t == 0) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) issue_a(i, cn, P ^ 1);
-            }
-            {
+                    for (int i = 0; i < 7; ++i) issue_a(i, cn, P ^ 1);
+                }
                 const bool more = jb + t + S < ns;
                 const int c3 = t + S >= 9 ? c + 1 : c, t3 = (t + S) % 9;
                 issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % S);
@@ -298,12 +336,12 @@ __global__ __launch_bounds__(T, (S == 3 ? 2 : 1)) void conv3x3_kernel(ConvParams
             // issue order within the step (the loop is instruction-issue bound: one wave per SIMD, and a 32-cycle MFMA
             // hides ~24 cycles of other issue): the next fragments' 12 LDS reads ride in the first four MFMA gaps so
             // the last four MFMAs cover their latency; the DMAs (1 KiB each, ~60 cycles of issue) one per gap
-            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);                 // VMEM read (first DMA piece)
+            if (!LOADER) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);    // VMEM read (first DMA piece)
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 if (g < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);               // MFMA
-                if (g < (t == 0 ? 8 : 1)) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+                if (!LOADER && g < (t == 0 ? 8 : 1)) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -443,6 +481,7 @@ int tile_width(int H, int W) {
 //   fixed     5 (launch, prologue, epilogue)
 //   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
 // e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
+int g_conv_loaders = 1;            // dsc_debug_set_conv_ring(400 / 401 / 402): nine-stage kernels without loader waves / by rule / always
 int g_conv_order = -1;             // dsc_debug_set_conv_ring(300 / 301): pixel tiles / channel blocks fastest within an XCD (-1: by shape)
 double g_conv_small_step = 0.26;   // us per step of a grid of <= 256 workgroups (dsc_debug_set_conv_ring(200 + hundredths))
 int auto_splits(int tiles, int nc, long long npix, int cout) {
@@ -482,7 +521,8 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
 extern "C" void dsc_debug_set_conv_ring(int stages) {
-    if (stages >= 300) g_conv_order = stages - 300;
+    if (stages >= 400) g_conv_loaders = stages - 400;
+    else if (stages >= 300) g_conv_order = stages - 300;
     else if (stages >= 200) g_conv_small_step = (stages - 200) / 100.0;
     else g_conv_ring = stages;
 }
@@ -541,7 +581,8 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     static bool attr_set = false;
     if (!attr_set) {
         const void* fns[] = {reinterpret_cast<const void*>(&conv3x3_kernel<16, 3>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 3>),
-                             reinterpret_cast<const void*>(&conv3x3_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9>)};
+                             reinterpret_cast<const void*>(&conv3x3_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9>),
+                             reinterpret_cast<const void*>(&conv3x3_kernel<16, 9, 4>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9, 4>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -556,11 +597,17 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     // ... and only while this stream owns the chip: with a second generation in flight the whole-LDS workgroups keep the other
     // stream's kernels off their CUs (dsc_set_tuning_profile)
     if (ring != 3 && ring != 9) ring = (total <= 256 && g_dsc_tuning_profile == DSC_TUNE_LATENCY) ? 9 : 3;
+    // the nine-stage ring has the CU to itself anyway.  In the step: 16-wide tiles 29.2 -> 25.0 us (160 workgroups), 21.2 ->
+    // 19.5 (64); the 8-wide kernel (8x8 level, two halo parities, 12 spilled registers at the 256 cap) 15.0 -> 16.0: not used
+    const bool loaders = ring == 9 && (g_conv_loaders == 2 || (g_conv_loaders == 1 && tw == 16));
+    const dim3 block8(T + 256);
     if (tw == 16) {
-        if (ring == 9) DSC_LAUNCH((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
+        if (loaders) DSC_LAUNCH((conv3x3_kernel<16, 9, 4>), grid, block8, (size_t)lds_bytes(9), st, p);
+        else if (ring == 9) DSC_LAUNCH((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
         else DSC_LAUNCH((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);
     } else {
-        if (ring == 9) DSC_LAUNCH((conv3x3_kernel<8, 9>), grid, block, (size_t)lds_bytes(9), st, p);
+        if (loaders) DSC_LAUNCH((conv3x3_kernel<8, 9, 4>), grid, block8, (size_t)lds_bytes(9), st, p);
+        else if (ring == 9) DSC_LAUNCH((conv3x3_kernel<8, 9>), grid, block, (size_t)lds_bytes(9), st, p);
         else DSC_LAUNCH((conv3x3_kernel<8, 3>), grid, block, (size_t)lds_bytes(3), st, p);
     }
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;

@@ -270,7 +270,7 @@ int dsc_conv3x3_supported(int B, int H, int W, int Cin, int Cout);
 void dsc_debug_set_conv_stamps(void* device_buffer);
 /* diagnostics: 3 / 9 = force the weight-tile ring depth, 0 = by grid size and tuning profile; 200 + n = the split-count
  * model's per-step time for grids of <= 256 workgroups (n / 100 us); 300 / 301 = pixel tiles / channel blocks fastest
- * within an XCD (default: by shape) */
+ * within an XCD (default: by shape); 400 / 401 / 402 = the nine-stage kernels without DMA-only loader waves / by rule / always */
 void dsc_debug_set_conv_ring(int stages);
 size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout, int splits);
 int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,

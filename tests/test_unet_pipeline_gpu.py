@@ -277,10 +277,15 @@ def test_conv3x3_and_gemm_profiles_give_equal_bytes(ops, B, Cin, Cout, H, W):
         for ring in (3, 9):
             lib.dsc_debug_set_conv_ring(ring)
             outs[ring] = (ops.conv3x3(x, w, b), None)
+        lib.dsc_debug_set_conv_ring(400)                      # the nine-stage kernel without / with its loader waves
+        outs["9 plain"] = (ops.conv3x3(x, w, b), None)
+        lib.dsc_debug_set_conv_ring(402)
+        outs["9 loaders"] = (ops.conv3x3(x, w, b), None)
     finally:
+        lib.dsc_debug_set_conv_ring(401)
         lib.dsc_debug_set_conv_ring(0)
         ops.set_tuning_profile("latency")
-    for k in ("throughput", 3, 9):
+    for k in ("throughput", 3, 9, "9 plain", "9 loaders"):
         assert torch.equal(outs[k][0], outs["latency"][0]), k
     if outs["latency"][1] is not None:
         assert torch.equal(outs["throughput"][1], outs["latency"][1])
