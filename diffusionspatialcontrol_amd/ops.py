@@ -347,9 +347,10 @@ DSC_GEMM_MAX_K = int(os.environ.get("DSC_GEMM_MAX_K", "640"))       # kernels fo
 USE_LN_FOLD = os.environ.get("DSC_LN_FOLD", "1") != "0"   # BasicTransformerBlock: LayerNorms folded into the GEMMs (dsc_linear_ln_f16)
 
 
-DSC_GEMM_MID_ROWS = int(os.environ.get("DSC_GEMM_MID_ROWS", "512")) if os.environ.get("DSC_GEMM_MID", "1") != "0" else 1 << 30    # 512 <= rows < 1024 (the 16x16 level at batch 1): the kernel up to K = 1280 - a wash per GEMM against the
+DSC_GEMM_MID_ROWS = int(os.environ.get("DSC_GEMM_MID_ROWS", "128")) if os.environ.get("DSC_GEMM_MID", "1") != "0" else 1 << 30    # 128 <= rows < 1024 (the 16x16 and 8x8 levels at batch 1): the kernel up to K = 1280 - a wash per GEMM against the
 DSC_GEMM_MID_K = int(os.environ.get("DSC_GEMM_MID_K", "1280"))      # library (QKV 14.0 vs 15.4 us, C->C 11.8 vs 11.1), but it lets the block's three LayerNorms fold into
-#                            its GEMMs (three add+LayerNorm launches of 6.5 us fewer) and K / V leave the QKV GEMM head-major
+#                            its GEMMs (three add+LayerNorm launches of 6.5 us fewer) and K / V leave the QKV GEMM head-major; the 8x8 level
+#                            (128 rows) the same: equal time in the step and in images/s, three launches fewer (tools/ab_bench.sh)
 
 
 def _gemm_rows_k_preferred(M, K, geglu=False):
