@@ -50,9 +50,10 @@ _SIGNATURES = {
                                     [ctypes.c_float, _vp, ctypes.c_float, ctypes.c_int, ctypes.c_uint, _vp,
                                      ctypes.c_size_t, _vp]),
     "dsc_self_attn_fwd": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 5 + [_i64p] * 4 + [ctypes.c_float, ctypes.c_int, _vp]),
-    "dsc_prepare_unet_input": (ctypes.c_int, [_vp] + [ctypes.c_float] * 3 + [_vp, _vp, _vp] + [ctypes.c_int] * 3 + [_vp]),
+    "dsc_prepare_unet_input": (ctypes.c_int, [_vp] + [ctypes.c_float] * 3 + [_vp, _vp, _vp] + [ctypes.c_int] * 3 +
+                               [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_cfg_dpmpp2m_step": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_float] * 8 + [_vp, _vp, _vp] +
-                             [ctypes.c_int] * 3 + [_vp]),
+                             [ctypes.c_int] * 3 + [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_dpmpp2m_update": (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_float] * 3 + [_vp, ctypes.c_int64, ctypes.c_int, _vp]),
     "dsc_groupnorm_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "dsc_groupnorm_silu": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int,

@@ -17,8 +17,21 @@ __device__ __forceinline__ h8_t pack8(const float (&f)[8]) {
     return v;
 }
 
+// the step's row of a per-generation table (the time-embedding projections of every ResNet block for this step's timestep,
+// computed for all steps before the loop) copied to every row of the static buffer the captured UNet step reads
+__device__ __forceinline__ void copy_row(const half_t* src, half_t* dst, int halfs, int copies) {
+    if (!src) return;
+    const int v8 = halfs / 8;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < (long long)v8 * copies; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / v8), c = (int)(i - (long long)r * v8);
+        *reinterpret_cast<h8_t*>(dst + (long long)r * halfs + c * 8) = *reinterpret_cast<const h8_t*>(src + c * 8);
+    }
+}
+
 __global__ __launch_bounds__(256) void prepare_kernel(const half_t* x, float c_in, float t, float sigma, half_t* x_in,
-                                                      float* t_buf, float* sigma_buf, int n_img, int chw) {
+                                                      float* t_buf, float* sigma_buf, int n_img, int chw,
+                                                      const half_t* row_src, half_t* row_dst, int row_halfs, int row_copies) {
+    copy_row(row_src, row_dst, row_halfs, row_copies);
     const long long n8 = (long long)n_img * chw / 8;
     const long long half_elems = (long long)n_img * chw;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -40,7 +53,9 @@ __global__ __launch_bounds__(256) void prepare_kernel(const half_t* x, float c_i
 __global__ __launch_bounds__(256) void step_kernel(half_t* x, const half_t* eps, half_t* old, float sigma, float g,
                                                    float a, float b, float c, float c_in_next, float t_next,
                                                    float sigma_next, half_t* x_in, float* t_buf, float* sigma_buf,
-                                                   int n_img, int chw) {
+                                                   int n_img, int chw,
+                                                   const half_t* row_src, half_t* row_dst, int row_halfs, int row_copies) {
+    copy_row(row_src, row_dst, row_halfs, row_copies);
     const long long half_elems = (long long)n_img * chw;
     const long long n8 = half_elems / 8;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -89,27 +104,40 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+namespace {
+int row_args_status(const void* row_src, const void* row_dst, int row_halfs, int row_copies) {
+    if (!row_src) return DSC_OK;
+    if (!row_dst || row_halfs <= 0 || row_copies <= 0) return DSC_ERR_BAD_ARG;
+    if (row_halfs % 8 != 0 || !al16(row_src) || !al16(row_dst)) return DSC_ERR_UNSUPPORTED;
+    return DSC_OK;
+}
+}  // namespace
+
 extern "C" int dsc_prepare_unet_input(const void* x, float c_in, float t, float sigma, void* x_in, float* t_buf,
-                                      float* sigma_buf, int n_img, int chw, int dtype, void* stream) {
+                                      float* sigma_buf, int n_img, int chw, int dtype,
+                                      const void* row_src, void* row_dst, int row_halfs, int row_copies, void* stream) {
     if (!x || !x_in || !t_buf || !sigma_buf || n_img <= 0 || chw <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16 || chw % 8 != 0 || !al16(x) || !al16(x_in)) return DSC_ERR_UNSUPPORTED;
+    if (const int rs = row_args_status(row_src, row_dst, row_halfs, row_copies)) return rs;
     const long long n8 = (long long)n_img * chw / 8;
     DSC_LAUNCH(prepare_kernel, dim3(grid_for(n8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const half_t*>(x), c_in, t, sigma, static_cast<half_t*>(x_in), t_buf, sigma_buf,
-                       n_img, chw);
+                       n_img, chw, static_cast<const half_t*>(row_src), static_cast<half_t*>(row_dst), row_halfs, row_copies);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 
 extern "C" int dsc_cfg_dpmpp2m_step(void* x, const void* eps, void* old, float sigma, float guidance, float a, float b,
                                     float c, float c_in_next, float t_next, float sigma_next, void* x_in, float* t_buf,
-                                    float* sigma_buf, int n_img, int chw, int dtype, void* stream) {
+                                    float* sigma_buf, int n_img, int chw, int dtype,
+                                    const void* row_src, void* row_dst, int row_halfs, int row_copies, void* stream) {
     if (!x || !eps || !old || !x_in || !t_buf || !sigma_buf || n_img <= 0 || chw <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16 || chw % 8 != 0 || !al16(x) || !al16(eps) || !al16(old) || !al16(x_in)) return DSC_ERR_UNSUPPORTED;
+    if (const int rs = row_args_status(row_src, row_dst, row_halfs, row_copies)) return rs;
     const long long n8 = (long long)n_img * chw / 8;
     DSC_LAUNCH(step_kernel, dim3(grid_for(n8)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<half_t*>(x), static_cast<const half_t*>(eps), static_cast<half_t*>(old), sigma,
                        guidance, a, b, c, c_in_next, t_next, sigma_next, static_cast<half_t*>(x_in), t_buf, sigma_buf,
-                       n_img, chw);
+                       n_img, chw, static_cast<const half_t*>(row_src), static_cast<half_t*>(row_dst), row_halfs, row_copies);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 

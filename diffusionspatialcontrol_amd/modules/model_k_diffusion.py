@@ -924,7 +924,10 @@ class StableDiffusionPipeline:
                 s = float(sigma[0])                              # the host needs sigma for (c_in, t): one sync per model call
                 c_in, _, t = kdm.step_scalars(s)
                 d = x.to(text.dtype).contiguous().clone()
-                ops.prepare_unet_input(d, c_in, t, s, st["x_in"], st["t"], st["sigma"])
+                row = None
+                if st["tadd"] is not None:                       # any sigma may be asked for: this call's embedding rows, now
+                    row = (self.unet.temb_add_table(torch.tensor([t], dtype=torch.float32, device=d.device))[0], st["tadd"])
+                ops.prepare_unet_input(d, c_in, t, s, st["x_in"], st["t"], st["sigma"], row=row)
                 set_control(s)
                 st["run"]()
                 # a = 0, b = 1, c = 0: d <- D = x - sigma (eps_u + g (eps_c - eps_u)); the "next input" it also writes is unused
@@ -1056,6 +1059,11 @@ class StableDiffusionPipeline:
             "compressed": None, "dense": None,
             "weight_func": weight_func,          # kept alive: the key holds its id
             "profile": ops.tuning_profile(),     # the launch rules baked into the capture (ops.set_tuning_profile)
+            # the time-embedding projections of all ResNet blocks for the step about to run: written by the sampler kernels
+            # (a row of the per-schedule table, _denoise_fused) instead of being recomputed by three launches inside every step
+            "tadd": (torch.zeros((rows, self.unet.temb_width()), device=dev, dtype=dt)
+                     if ops.USE_TEMB_HOIST and hasattr(self.unet, "temb_add_table") and dt == torch.float16 else None),
+            "temb_tab": None, "temb_key": None,
             "image_embeds": None if ack is None else [e.clone() for e in ack["image_embeds"]],
         }
         if comp_cpu is not None:
@@ -1087,6 +1095,8 @@ class StableDiffusionPipeline:
                 extra.update({"down_block_additional_residuals": down, "mid_block_additional_residual": mid})
             if st["ad"] is not None:                # T2I-Adapter features, gated per call (0 = the reference passes none)
                 extra["down_intrablock_additional_residuals"] = [v * st["ad"]["gate"] for v in st["ad"]["state"]]
+            if st["tadd"] is not None:
+                extra["temb_adds"] = st["tadd"]
             return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw, **extra).sample
 
         side = torch.cuda.Stream(device=dev)
@@ -1223,7 +1233,16 @@ class StableDiffusionPipeline:
             torch.cuda.synchronize()
             t1 = time.perf_counter()
         c_in, _, t = kdm.step_scalars(sig[0])
-        ops.prepare_unet_input(x, c_in, t, sig[0], st["x_in"], st["t"], st["sigma"])
+        tab = None
+        if st["tadd"] is not None:
+            # the schedule's timesteps are known here: every step's embedding rows in one table (kept while the schedule repeats)
+            tkey = tuple(sig[:len(coeffs)])
+            if st["temb_key"] != tkey:
+                ts = [float(kdm.step_scalars(s_)[2]) for s_ in sig[:len(coeffs)]]
+                st["temb_tab"] = self.unet.temb_add_table(torch.tensor(ts, dtype=torch.float32, device=x.device))
+                st["temb_key"] = tkey
+            tab = st["temb_tab"]
+        ops.prepare_unet_input(x, c_in, t, sig[0], st["x_in"], st["t"], st["sigma"], row=None if tab is None else (tab[0], st["tadd"]))
         for i, (a, b, c) in enumerate(coeffs):
             if start_time > 0 and timeout > 0:
                 assert (time.time() - start_time) < timeout, "inference process timed out"
@@ -1232,7 +1251,8 @@ class StableDiffusionPipeline:
             c_in_n, _, t_n = kdm.step_scalars(nxt) if nxt > 0 else (1.0, 0.0, 0.0)
             # x <- a*x + b*D + c*D_old with D = x - sigma*(eps_u + g*(eps_c - eps_u)); also writes next x_in/t/sigma
             ops.cfg_dpmpp2m_step(x, st["eps"], old, sig[i], guidance_scale, a, b, c, c_in_n, t_n, max(nxt, 1e-10),
-                                 st["x_in"], st["t"], st["sigma"])
+                                 st["x_in"], st["t"], st["sigma"],
+                                 row=(tab[i + 1], st["tadd"]) if tab is not None and i + 1 < len(coeffs) else None)
         if x.is_cuda:
             done = st.get("done")
             if done is None:

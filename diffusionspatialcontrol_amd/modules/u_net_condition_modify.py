@@ -704,23 +704,43 @@ class _EncoderHalf:
             x = attn(x, encoder_hidden_states, cross_attention_kwargs)
         return self.mid_block.resnets[1](x, temb_act, tadd[self.mid_block.resnets[1]])
 
-    def _all_temb_adds(self, temb_act):
+    def _temb_all(self, temb_act):
         """the per-ResNet `time_emb_proj(silu(temb))` GEMMs ([B,1280] x [cout,1280]; 22 in the SD1.5 UNet) as ONE GEMM over
-        the concatenated weights; returns {resnet: [B, cout] view}.  Offsets are multiples of 8 (16-byte aligned rows)."""
+        the concatenated weights: [B, sum of cout] (conv1's bias folded in, ResnetBlock2D.temb_bias)"""
         res = self._resnets()
         deps = tuple(p for r in res for p in (r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias))
         W, Bv = _derived(self, "temb", deps, lambda: (torch.cat([r.time_emb_proj.weight for r in res]).contiguous(),
                                                        torch.cat([r.time_emb_proj.bias + r.conv1.bias for r in res])))
         if temb_act.is_cuda and temb_act.dtype == torch.float16 and temb_act.shape[0] <= 8:
-            allp = ops.linear_rows(temb_act, W, Bv)
-        else:
-            allp = F.linear(temb_act, W, Bv)
+            return ops.linear_rows(temb_act, W, Bv)
+        return F.linear(temb_act, W, Bv)
+
+    def _temb_views(self, allp):
+        """{resnet: [B, cout] view of its columns}.  Offsets are multiples of 8 (16-byte aligned rows)."""
         out, off = {}, 0
-        for r in res:
+        for r in self._resnets():
             n = r.time_emb_proj.out_features
             out[r] = allp[:, off:off + n]
             off += n
         return out
+
+    def _all_temb_adds(self, temb_act):
+        return self._temb_views(self._temb_all(temb_act))
+
+    def temb_width(self):
+        return sum(r.time_emb_proj.out_features for r in self._resnets())
+
+    def temb_add_table(self, timesteps):
+        """[len(timesteps), temb_width()]: row i = what `_temb_all` gives inside a forward at timestep i - for a caller that
+        knows its timesteps up front (the fused denoising loop) and passes a row back as `forward(..., temb_adds=...)`.  The
+        embedding depends on the timestep alone in this UNet (no class / added-condition embedding)."""
+        ts = timesteps.reshape(-1).float()
+        rows = []
+        for i in range(0, ts.numel(), 8):                    # the few-row GEMV kernels take at most 8 rows
+            chunk = ts[i:i + 8]
+            probe = torch.empty((chunk.numel(), 1), device=ts.device, dtype=self.conv_in.weight.dtype)
+            rows.append(self._temb_all(self._time_act(probe, chunk)))
+        return torch.cat(rows, dim=0).contiguous()
 
     # ---- processor plumbing (reference :689-749)
     @property
@@ -799,10 +819,12 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
-                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True):
+                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True, temb_adds=None):
         if attention_mask is not None or encoder_attention_mask is not None:
             raise NotImplementedError("attention masks are not on the hot path (never passed by app.py)")
-        temb_act = self._time_act(sample, timestep)
+        # temb_adds: a [B, temb_width()] buffer holding this timestep's rows of temb_add_table() - the time-embedding path
+        # is then not run (the captured step of the fused loop: its caller refreshes the buffer between replays)
+        temb_act = None if temb_adds is not None else self._time_act(sample, timestep)
         self._to_channels_last_once()
         if getattr(self, "encoder_hid_proj", None) is not None and self.config.get("encoder_hid_dim_type") == "ip_image_proj":
             # reference :1030-1037 - the IP-Adapter image tokens travel with the text as a tuple
@@ -811,7 +833,7 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
                                  "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
             encoder_hidden_states = (encoder_hidden_states, self.encoder_hid_proj(added_cond_kwargs.get("image_embeds")))
         x = self._conv_in(sample)
-        tadd = self._all_temb_adds(temb_act)
+        tadd = self._temb_views(temb_adds) if temb_adds is not None else self._all_temb_adds(temb_act)
         if down_intrablock_additional_residuals is None and mid_block_additional_residual is None \
                 and down_block_additional_residuals is not None:
             # legacy T2I-Adapter usage (reference :1200-1211): residuals without a mid residual are intra-block ones

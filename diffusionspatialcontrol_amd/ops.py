@@ -37,6 +37,9 @@ def _workspace(device, nbytes):
     return torch.empty(max(nbytes, 16) // 8 + 1, dtype=torch.float64, device=device)
 
 
+USE_TEMB_HOIST = os.environ.get("DSC_TEMB_HOIST", "1") != "0"   # fused loop: the time-embedding path once per schedule, not per step
+
+
 TUNING_PROFILES = {"latency": 0, "throughput": 1}       # DSC_TUNE_LATENCY / DSC_TUNE_THROUGHPUT (include/dsc_hip.h)
 
 
@@ -590,6 +593,7 @@ def linear_rows(x, weight, bias=None, silu_out=False, sinusoid_dim=0):
     if sinusoid_dim:
         if x.dtype != torch.float32 or x.dim() != 1 or sinusoid_dim != K:
             raise ValueError("linear_rows: sinusoid input is an fp32 [M] tensor and sinusoid_dim == weight.shape[1]")
+        x = x.contiguous()                                   # (an expanded scalar timestep has stride 0: the kernel reads x[m])
         M, ldx = x.shape[0], 0
     else:
         x = x if x.stride(-1) == 1 else x.contiguous()
@@ -656,22 +660,34 @@ GRAPHS_ENABLED = True      # the fused pipeline captures the UNet step into a HI
 PROTOCOL_GRAPH = os.environ.get("DSC_PROTOCOL_GRAPH", "1") != "0"   # protocol-mode model calls replay the same graph
 
 
-def prepare_unet_input(x, c_in, t, sigma, x_in, t_buf, sigma_buf):
-    """x_in = [x; x] * c_in, t_buf[:] = t, sigma_buf[0] = sigma (dsc_prepare_unet_input)."""
+def _row_args(row):
+    """(src, dst, halfs, copies) of the optional row broadcast of the sampler kernels: row = (src [n] fp16, dst [copies, n] fp16)"""
+    if row is None:
+        return None, None, 0, 0
+    src, dst = row
+    _require_gpu(src, dst)
+    if src.dtype != torch.float16 or dst.dtype != torch.float16 or not dst.is_contiguous() or src.stride(-1) != 1 \
+            or dst.dim() != 2 or dst.shape[1] != src.numel():
+        raise ValueError("row broadcast: fp16 source [n] and contiguous destination [copies, n]")
+    return _p(src), _p(dst), src.numel(), dst.shape[0]
+
+
+def prepare_unet_input(x, c_in, t, sigma, x_in, t_buf, sigma_buf, row=None):
+    """x_in = [x; x] * c_in, t_buf[:] = t, sigma_buf[0] = sigma (dsc_prepare_unet_input); row: see _row_args."""
     _require_gpu(x, x_in, t_buf, sigma_buf)
     n_img = x.shape[0]
     rc = _lib.load_library().dsc_prepare_unet_input(_p(x), c_in, t, sigma, _p(x_in), _p(t_buf), _p(sigma_buf), n_img,
-                                                    x.numel() // n_img, 0, _stream_ptr(x))
+                                                    x.numel() // n_img, 0, *_row_args(row), _stream_ptr(x))
     _lib.check(rc, "dsc_prepare_unet_input")
 
 
-def cfg_dpmpp2m_step(x, eps, old, sigma, guidance, a, b, c, c_in_next, t_next, sigma_next, x_in, t_buf, sigma_buf):
-    """One launch: CFG combine + eps->denoised + DPM++ 2M update (in place on x, old) + next UNet input."""
+def cfg_dpmpp2m_step(x, eps, old, sigma, guidance, a, b, c, c_in_next, t_next, sigma_next, x_in, t_buf, sigma_buf, row=None):
+    """One launch: CFG combine + eps->denoised + DPM++ 2M update (in place on x, old) + next UNet input (+ the row broadcast)."""
     _require_gpu(x, eps, old, x_in)
     n_img = x.shape[0]
     rc = _lib.load_library().dsc_cfg_dpmpp2m_step(_p(x), _p(eps), _p(old), sigma, guidance, a, b, c, c_in_next, t_next,
                                                   sigma_next, _p(x_in), _p(t_buf), _p(sigma_buf), n_img,
-                                                  x.numel() // n_img, 0, _stream_ptr(x))
+                                                  x.numel() // n_img, 0, *_row_args(row), _stream_ptr(x))
     _lib.check(rc, "dsc_cfg_dpmpp2m_step")
 
 

@@ -171,11 +171,17 @@ int dsc_self_attn_fwd(const void* q, const void* k, const void* v, void* out,
  * x, old: fp16 [n_img, chw]; eps, x_in: fp16 [2 n_img, chw]; t_buf fp32 [2 n_img]; sigma_buf fp32 [1].
  * dsc_prepare_unet_input does only the last line (before the first step).  chw % 8 == 0, 16-byte aligned pointers.
  */
+/* row_src (optional, NULL = none): row_halfs fp16 values copied to each of the row_copies rows of row_dst in the same launch -
+ * the pipeline keeps the per-ResNet time-embedding projections of ALL steps in a table computed once per schedule (they depend on
+ * the timestep only, reference u_net_condition_modify.py:1040-1060 + diffusers ResnetBlock2D.time_emb_proj) and hands the
+ * coming step's row to the static buffer the captured UNet step reads: three launches per step fewer.  row_halfs % 8 == 0. */
 int dsc_prepare_unet_input(const void* x, float c_in, float t, float sigma,
-                           void* x_in, float* t_buf, float* sigma_buf, int n_img, int chw, int dtype, void* stream);
+                           void* x_in, float* t_buf, float* sigma_buf, int n_img, int chw, int dtype,
+                           const void* row_src, void* row_dst, int row_halfs, int row_copies, void* stream);
 int dsc_cfg_dpmpp2m_step(void* x, const void* eps, void* old, float sigma, float guidance,
                          float a, float b, float c, float c_in_next, float t_next, float sigma_next,
-                         void* x_in, float* t_buf, float* sigma_buf, int n_img, int chw, int dtype, void* stream);
+                         void* x_in, float* t_buf, float* sigma_buf, int n_img, int chw, int dtype,
+                         const void* row_src, void* row_dst, int row_halfs, int row_copies, void* stream);
 /* out = a*x + b*denoised + c*old  (old may be NULL when c == 0): the sampler update alone, for callers that keep
  * the reference's `sampler(model_fn, x, sigmas=...)` control flow.  n elements, n % 8 == 0. */
 int dsc_dpmpp2m_update(const void* x, const void* denoised, const void* old, float a, float b, float c,

@@ -374,3 +374,39 @@ def test_step_is_recaptured_when_the_tuning_profile_changes():
         ops.set_tuning_profile("latency")
     scale = a.abs().max().item()
     assert (a - b).abs().max().item() < 2e-2 * scale and (a - c).abs().max().item() < 2e-2 * scale
+
+
+def test_time_embedding_rows_from_the_schedule_table(sd15):
+    """The fused loop computes every step's time-embedding projections once per schedule (UNet.temb_add_table) and the sampler
+    kernels hand the coming step's row to the captured step (ops.USE_TEMB_HOIST): a table row equals what the forward computes
+    for that timestep, and the loop's latents equal the ones of the per-step form bit for bit."""
+    import inspect
+    from diffusionspatialcontrol_amd import ops
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
+    emb, ids, state, _ = _inputs(512, 2)
+    rs = _region_tables(sd15.pipe, state, 512, ids)
+    sig = sd15.pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
+    sigmas = torch.tensor(sig[:5]).half()
+    wf = inspect.signature(sd15.pipe.txt2img).parameters["weight_func"].default
+    text = torch.cat([emb[0:1], emb[1:2]]).half()
+    x0 = _latent(0)[None].half().cuda() * (sigmas[0].cuda() ** 2 + 1) ** 0.5
+    unet = sd15.unet
+    ts = torch.tensor([999.0, 500.25, 3.0, 41.5, 0.0, 123.0, 77.7, 8.0, 640.0], device="cuda")
+    tab = unet.temb_add_table(ts)
+    assert tab.shape == (9, unet.temb_width())
+    for i in (0, 4, 8):                                                        # rows of a 9-row table vs a 2-row forward
+        probe = torch.empty((2, 1), device="cuda", dtype=torch.float16)
+        want = unet._temb_all(unet._time_act(probe, ts[i:i + 1]))
+        assert torch.equal(tab[i], want[0]) and torch.equal(tab[i], want[1])
+    outs = {}
+    saved = ops.USE_TEMB_HOIST
+    try:
+        for hoist in (True, False):
+            ops.USE_TEMB_HOIST = hoist
+            pipe = StableDiffusionPipeline(None, None, FakeTokenizer(), unet, SD15Scheduler())
+            outs[hoist] = pipe._denoise_fused(x0, sigmas.cuda(), text.cuda(), rs, wf, 7.5, 1, {}, -1, 0).float().cpu()
+            st = next(iter(pipe._graphs.values()))
+            assert (st["tadd"] is not None) == hoist
+    finally:
+        ops.USE_TEMB_HOIST = saved
+    assert torch.isfinite(outs[True]).all() and torch.equal(outs[True], outs[False])

@@ -356,6 +356,10 @@ def test_linear_rows_time_embedding(ops, M):
     h_ref = F.silu((emb.float() @ w1.float().t() + b1.float()).half().float()).half()
     h = ops.linear_rows(t.cuda(), w1.cuda(), b1.cuda(), silu_out=True, sinusoid_dim=320)
     assert h.shape == (M, 1280)
+    # one timestep expanded over the batch (a scheduler's 0-dim timestep: stride 0, and its neighbour in memory is the NEXT timestep)
+    both = torch.tensor([float(t[0]), 3.0]).cuda()
+    he = ops.linear_rows(both[0:1].expand(M), w1.cuda(), b1.cuda(), silu_out=True, sinusoid_dim=320)
+    assert all(torch.equal(he[m], h[0]) for m in range(M))
     assert torch.all((h.float().cpu() - h_ref.float()).abs() <= 2e-3 * h_ref.float().abs() + 2e-3), (h.float().cpu() - h_ref.float()).abs().max()
     y_ref = F.silu((h_ref.float() @ w2.float().t() + b2.float()).half().float())
     y = ops.linear_rows(h_ref.cuda(), w2.cuda(), b2.cuda(), silu_out=True)
