@@ -350,6 +350,10 @@ class _RegionProcessor:
             else:
                 key = attn.to_k(encoder_hidden_states)
                 value = attn.to_v(encoder_hidden_states)
+            if not is_self and key.shape[0] != query.shape[0] and key.shape[0] % query.shape[0] == 0:
+                # shared CFG prefix (UNet2DConditionModel.forward): up to the first cross-attention the unconditional and
+                # the conditional rows of the batch are the same numbers and were computed once - from here on they differ
+                query = query.repeat(key.shape[0] // query.shape[0], 1, 1)
             B, L, C = query.shape
             d = C // H
             S = key.shape[1]
@@ -394,7 +398,10 @@ class _RegionProcessor:
         to_out = attn.to_out[0]
         if _ln_fold is not None:
             # the block's `x = attn(norm(x)) + x` add and the next LayerNorm's row statistics ride in this GEMM's epilogue
-            return ops.linear_ln(hidden_states, to_out.weight, to_out.bias, residual=_ln_fold.residual, ln_stats=True)
+            res = _ln_fold.residual
+            if res.shape[0] != hidden_states.shape[0]:       # shared CFG prefix: the residual stream was computed once per image
+                res = res.repeat(hidden_states.shape[0] // res.shape[0], 1, 1)
+            return ops.linear_ln(hidden_states, to_out.weight, to_out.bias, residual=res, ln_stats=True)
         hidden_states = ops.linear(hidden_states, to_out.weight, to_out.bias) if type(to_out) is nn.Linear \
             else to_out(hidden_states)
         hidden_states = attn.to_out[1](hidden_states)

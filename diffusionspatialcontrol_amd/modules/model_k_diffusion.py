@@ -1097,6 +1097,8 @@ class StableDiffusionPipeline:
                 extra["down_intrablock_additional_residuals"] = [v * st["ad"]["gate"] for v in st["ad"]["state"]]
             if st["tadd"] is not None:
                 extra["temb_adds"] = st["tadd"]
+            if ops.USE_CFG_SHARED_PREFIX and st["cn"] is None and st["ad"] is None and hasattr(self.unet, "temb_add_table"):
+                extra["cfg_shared_prefix"] = True    # x_in = [x; x] (ops.prepare_unet_input / cfg_dpmpp2m_step), one timestep
             return self.unet(st["x_in"], st["t"], encoder_hidden_states=st["text"], cross_attention_kwargs=kw, **extra).sample
 
         side = torch.cuda.Stream(device=dev)

@@ -480,8 +480,10 @@ class BasicTransformerBlock(nn.Module):
         # and cross-attention, as in diffusers' BasicTransformerBlock)
         _, h = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         x, h = ops.add_layernorm(x, self.attn1(h, None, **kw), self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        x, h = ops.add_layernorm(x, self.attn2(h, encoder_hidden_states, **kw), self.norm3.weight, self.norm3.bias,
-                                 self.norm3.eps)
+        a2 = self.attn2(h, encoder_hidden_states, **kw)
+        if a2.shape[0] != x.shape[0]:                            # shared CFG prefix: the cross-attention output has the full batch
+            x = x.repeat(a2.shape[0] // x.shape[0], 1, 1)
+        x, h = ops.add_layernorm(x, a2, self.norm3.weight, self.norm3.bias, self.norm3.eps)
         return self.ff(h, residual=x)
 
 
@@ -510,10 +512,13 @@ class Transformer2DModel(nn.Module):
             t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, encoder_hidden_states, cross_attention_kwargs, stats=st if i == 0 else None)
+        res = _tokens(x)
+        if res.shape[0] != t.shape[0]:                           # shared CFG prefix: x came in once per image
+            res = res.repeat(t.shape[0] // res.shape[0], 1, 1)
         if self.use_linear_projection:
-            t = ops.linear(t, self.proj_out.weight, self.proj_out.bias, residual=_tokens(x))
+            t = ops.linear(t, self.proj_out.weight, self.proj_out.bias, residual=res)
         else:
-            t = self.proj_out.tokens(t, residual=_tokens(x))
+            t = self.proj_out.tokens(t, residual=res)
         return _image(t, h, w)
 
 
@@ -688,6 +693,9 @@ class _EncoderHalf:
                 x = res(x, temb_act, tadd[res])
                 if blk.has_attn:
                     x = blk.attentions[j](x, encoder_hidden_states, cross_attention_kwargs)
+                    if x.shape[0] != skips[0].shape[0]:          # shared CFG prefix ended here: the skips so far, per row
+                        skips = [torch.cat([s_] * (x.shape[0] // s_.shape[0])).contiguous(memory_format=torch.channels_last)
+                                 for s_ in skips]
                     if j == last and extra is not None:
                         x = x + extra.to(x.dtype)
                 skips.append(x)
@@ -819,7 +827,8 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
-                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True, temb_adds=None):
+                down_intrablock_additional_residuals=None, encoder_attention_mask=None, return_dict=True, temb_adds=None,
+                cfg_shared_prefix=False):
         if attention_mask is not None or encoder_attention_mask is not None:
             raise NotImplementedError("attention masks are not on the hot path (never passed by app.py)")
         # temb_adds: a [B, temb_width()] buffer holding this timestep's rows of temb_add_table() - the time-embedding path
@@ -832,7 +841,15 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
                 raise ValueError(f"{self.__class__} has the config param `encoder_hid_dim_type` set to 'ip_image_proj' which "
                                  "requires the keyword argument `image_embeds` to be passed in  `added_conditions`")
             encoder_hidden_states = (encoder_hidden_states, self.encoder_hid_proj(added_cond_kwargs.get("image_embeds")))
-        x = self._conv_in(sample)
+        # cfg_shared_prefix (the caller's promise: rows [n:] of `sample` and of the time embedding equal rows [:n] - classifier-free
+        # guidance's [x; x] input): everything before the first cross-attention is the same for both halves and runs on rows
+        # [:n] only (conv_in, the first ResNet block, the first transformer block's GroupNorm / proj_in / self-attention / to_q);
+        # the cross-attention processor repeats the shared rows against the full batch of text keys, and the batch is whole
+        # again from there on (_run_down repeats the skip tensors collected so far)
+        share = bool(cfg_shared_prefix) and sample.shape[0] % 2 == 0 and down_block_additional_residuals is None \
+            and down_intrablock_additional_residuals is None and self.down_blocks[0].has_attn \
+            and not isinstance(encoder_hidden_states, tuple)
+        x = self._conv_in(sample[:sample.shape[0] // 2] if share else sample)
         tadd = self._temb_views(temb_adds) if temb_adds is not None else self._all_temb_adds(temb_act)
         if down_intrablock_additional_residuals is None and mid_block_additional_residual is None \
                 and down_block_additional_residuals is not None:

@@ -37,6 +37,7 @@ def _workspace(device, nbytes):
     return torch.empty(max(nbytes, 16) // 8 + 1, dtype=torch.float64, device=device)
 
 
+USE_CFG_SHARED_PREFIX = os.environ.get("DSC_CFG_PREFIX", "1") != "0"   # captured step: the layers in front of the first cross-attention once per image
 USE_TEMB_HOIST = os.environ.get("DSC_TEMB_HOIST", "1") != "0"   # fused loop: the time-embedding path once per schedule, not per step
 
 
