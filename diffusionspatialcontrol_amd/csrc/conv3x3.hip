@@ -477,13 +477,19 @@ int tile_width(int H, int W) {
 }
 
 // Split count from a cost model fitted to tools/mb_conv3.py on MI355X (us):
-//   loop      9 * nc / S steps x 0.26 us, x1.15 once two workgroups share a CU (> 256), x wgs/512 beyond 512
+//   loop      9 * nc / S steps x 0.26 us (x1.15 once two workgroups share a CU (> 256), x wgs/512 beyond 512); g_conv_small_step
+//             for grids of <= 256 workgroups
 //   fixed     5 (launch, prologue, epilogue)
 //   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
 // e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
 int g_conv_loaders = 1;            // dsc_debug_set_conv_ring(400 / 401 / 402): nine-stage kernels without loader waves / by rule / always
 int g_conv_order = -1;             // dsc_debug_set_conv_ring(300 / 301): pixel tiles / channel blocks fastest within an XCD (-1: by shape)
-double g_conv_small_step = 0.26;   // us per step of a grid of <= 256 workgroups (dsc_debug_set_conv_ring(200 + hundredths))
+// us per step the model charges a grid of <= 256 workgroups (dsc_debug_set_conv_ring(200 + hundredths)).  Chosen on images/s,
+// not on the kernels' own times (tools/ab_bench.sh, one box): 0.26 / 0.22 / 0.18 / 0.14 / 0.10 -> 11.32 / 11.40 / 11.59 / 11.67 /
+// 11.66 images/s with two generations in flight, 8.11-8.19 one at a time whatever the value: few splits mean fewer workgroups and
+// fewer partial sums through the L2 - work, which counts when two streams share the chip - and with the nine-stage ring and the
+// loader waves the one-workgroup-per-CU launches are no slower for the stream that owns them
+double g_conv_small_step = 0.14;
 int auto_splits(int tiles, int nc, long long npix, int cout) {
     int best = 1;
     double best_t = 1e30;
