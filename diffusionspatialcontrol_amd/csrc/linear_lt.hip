@@ -18,6 +18,8 @@
 #include <tuple>
 #include "dsc_hip.h"
 
+extern int g_dsc_tuning_profile;     // c_api.hip
+
 namespace {
 
 constexpr int kMaxCand = 64;
@@ -61,6 +63,10 @@ bool allow_workspace() {
 }
 // the size the library is TOLD it may use: 0 unless the workspace-needing algorithms were asked for (A/B timing only)
 size_t ws_bytes() { return allow_workspace() ? kWsBytes : 0; }
+bool lt_profile_aware() {
+    static const bool v = [] { const char* e = getenv("DSC_LT_PROFILE_AWARE"); return !e || atoi(e) != 0; }();
+    return v;
+}
 std::map<std::tuple<int64_t, int, int, int64_t, int64_t, int64_t, int, int>, Plan> g_plans;
 long long g_stat_seen = 0, g_stat_dropped_ws = 0;          // heuristic candidates seen / dropped for needing a workspace
 
@@ -207,8 +213,13 @@ extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias,
     if (bias) hipblasLtMatmulDescSetAttribute(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
     if (!plan->tuned) tune_plan(*plan, x, w, residual, out, M, K, ldx, hs);
     const float alpha = 1.f, beta = residual ? 1.f : 0.f;
+    // Which algorithm: the cold-timed fastest serves the stream that owns the chip; with several generations in flight
+    // (DSC_TUNE_THROUGHPUT) the heuristic's own first choice gave +1.1 % images/s (11.57 vs 11.44; -0.8 % one at a time) -
+    // the timed winners buy their latency with more workgroups / more traffic, which a shared chip pays for.
+    const hipblasLtMatmulAlgo_t* algo = (g_dsc_tuning_profile == DSC_TUNE_THROUGHPUT && plan->n_cand > 0 && lt_profile_aware())
+                                            ? &plan->cand[0] : &plan->algo;
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta,
-                                               residual ? residual : out, plan->c, out, plan->d, &plan->algo,
+                                               residual ? residual : out, plan->c, out, plan->d, algo,
                                                workspace_for(), ws_bytes(), hs);
     return st == HIPBLAS_STATUS_SUCCESS ? DSC_OK : DSC_ERR_LAUNCH;
 }
