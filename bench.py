@@ -475,12 +475,15 @@ def main():
     if nfl > 1:
         # the launch rules for generations that SHARE the chip (include/dsc_hip.h, dsc_set_tuning_profile): the legs above ran
         # under "latency"; every slot re-captures its step under "throughput" here, outside the timed region
+        ref_same_rules = out
         if a.tuning_profile == "auto":
             ops.set_tuning_profile("throughput")
             for s_i, st in enumerate(streams):
                 with torch.cuda.stream(st):
-                    generate(s_i)
+                    o_ = generate(s_i)
                 torch.cuda.synchronize()
+                if s_i == 0:
+                    ref_same_rules = o_              # one generation alone on the chip under the in-flight leg's launch rules
         progress = [0, time.monotonic()]
         outs, errs = [None] * nfl, []
         todo, todo_lock = iter(range(a.steps)), threading.Lock()
@@ -522,14 +525,18 @@ def main():
 
         dt, slot_outs = timed(in_flight)
         rates_fl = per_rank()
-        # every generation has the same inputs and every kernel is bit-reproducible: the slots' last results and the
-        # one-at-a-time result must be EQUAL - a free check on every run that the generations in flight did not interfere
-        slots_agree = all(torch.equal(o, out) for o in slot_outs)
+        # every generation has the same inputs and every kernel is bit-reproducible: the slots' last results and the result of a
+        # generation that ran ALONE under the same launch rules must be EQUAL - a free check on every run that the generations in
+        # flight did not interfere.  (Against the one-at-a-time leg, which runs under the latency rules, the latents agree to
+        # rounding: the two profiles' own kernels give equal bytes, but a library GEMM may be run by another algorithm.)
+        slots_agree = all(torch.equal(o, ref_same_rules) for o in slot_outs)
+        prof_diff = max(float((o.float() - out.float()).abs().max().item()) for o in slot_outs)
         if res is not None:
             res["one_generation_at_a_time"] = {"value": res["value"], "unit": "images/s", "ms_per_generation": res["ms_per_step"],
                                                "note": "the same K generations with one in flight (latency of one image)"}
             res["value"], res["ms_per_step"] = round(images / dt, 4), round(dt / a.steps * 1e3, 2)
             res["config"].update({"generations_in_flight": nfl, "slots_equal_one_at_a_time": slots_agree,
+                                  "max_abs_diff_between_the_profiles_latents": round(prof_diff, 6),
                                   "tuning_profile": {"one_generation_at_a_time": "latency" if a.tuning_profile == "auto" else a.tuning_profile,
                                                      "in_flight": ops.tuning_profile()},
                                   "per_rank_images_per_s": rates_fl, "max_over_ranks_s": round(dt, 4),
