@@ -513,6 +513,9 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         // that issue their own DMA; at 8 images the 4-wave workgroups win (480 vs 505 us)
         // (staggered: 64.0 us against 66.6 for the same kernel with all eight waves in phase)
         if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return compact ? launch<3, 8, 2, 5, 1, true>(p, st) : launch<3, 8, 2, 0, 2, true>(p, st);
+        // one image's 8 heads (the shared CFG prefix runs the first self-attention once per image): 256 workgroups of 128 query
+        // rows, one per CU - four computing waves + two loader waves 43.4 us against 51.8 for the four waves issuing their own DMA
+        if (v == 0 && compact && wg4 > 128 && wg4 <= 256) return launch<3, 4, 3, 5, 2>(p, st);
         if (v == 0 && compact && wg4 >= 256) return launch<3, 4, 2, 5, 0>(p, st);
     }
     // 15 / 16: 2 / 4 computing waves + FOUR loader waves, any head dim - the small-L levels (d = 80 at 32x32, d = 160 at 16x16)

@@ -19,7 +19,10 @@ def tm_graph(fn, n=20, reps=5):
     for _ in range(reps): g.replay()
     e.record(); e.synchronize()
     return s.elapsed_time(e) / (n * reps) * 1e3
-for (B, H, L, d) in [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160), (16, 8, 4096, 40), (2, 10, 4096, 64)]:
+shapes = [(2, 8, 4096, 40), (2, 8, 1024, 80), (2, 8, 256, 160), (2, 8, 64, 160), (16, 8, 4096, 40), (2, 10, 4096, 64), (1, 8, 4096, 40)]
+if os.environ.get("SHAPE"):                      # SHAPE=B,H,L,d: that shape only
+    shapes = [tuple(int(v) for v in os.environ["SHAPE"].split(","))]
+for (B, H, L, d) in shapes:
     qkv = torch.randn(B, L, 3 * H * d, device=dev).half(); C = H * d
     q, k, v = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
     if os.environ.get("HM", "1") == "1":       # head-major K / V, as dsc_linear_qkv_f16 writes them
