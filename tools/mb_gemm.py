@@ -27,11 +27,12 @@ for (M, N, K, geglu) in [(8192, 320, 320, 0), (8192, 960, 320, 0), (8192, 2560, 
     from diffusionspatialcontrol_amd import _lib
     lib = _lib.load_library()
     res = {}
-    for stg in (3, 2, 643, 642, 3, 2, 643, 642):
+    # dsc_debug_set_gemm_stages encoding (include/dsc_hip.h): 9xxxx = no loader waves, 1xxxxx = no 128-column tiles
+    for stg in (190003, 190002, 190643, 190642, 190003, 190002, 190643, 190642):
         lib.dsc_debug_set_gemm_stages(stg)
         t = tm_graph(lambda: ops.linear(x, w, b, geglu=True)) if geglu else tm_graph(lambda: ops.linear(x, w, b, residual=r))
         res[stg] = min(res.get(stg, 1e9), t)
     lib.dsc_debug_set_gemm_stages(0)
     t2 = tm_graph(lambda: ops.geglu(F.linear(x, w, b))) if geglu else tm_graph(lambda: F.linear(x, w, b) + r)
     fl = 2.0 * M * N * K
-    print(f"M{M} N{N} K{K} {'geglu' if geglu else 'bias+res'}: ours 128x64 tiles, 3 / 2 stages {res[3]:7.2f} / {res[2]:7.2f} us   64x64 tiles {res[643]:7.2f} / {res[642]:7.2f} us   hipBLASLt+epilogue kernels {t2:7.2f} us ({fl/t2/1e6:5.0f} TF)", flush=True)
+    print(f"M{M} N{N} K{K} {'geglu' if geglu else 'bias+res'}: ours 128x64 tiles, 3 / 2 stages {res[190003]:7.2f} / {res[190002]:7.2f} us   64x64 tiles {res[190643]:7.2f} / {res[190642]:7.2f} us   hipBLASLt+epilogue kernels {t2:7.2f} us ({fl/t2/1e6:5.0f} TF)", flush=True)
