@@ -10,14 +10,30 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdsc_hip.so")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
+
+
+STAMP = os.path.join(HERE, "_obj", "sources.sha256")
+
+
+def source_hash():
+    """sha256 over the names and bytes of every file the library is built from (csrc/*, include/dsc_hip.h) and the compiler
+    flags: a stale .so that merely has a newer mtime than the sources (a checkout, a copied tree) is rebuilt"""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sorted(f for f in glob.glob(os.path.join(CSRC, "*")) if os.path.isfile(f)) + [os.path.join(ROOT, "include", "dsc_hip.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def needs_build():
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = glob.glob(os.path.join(CSRC, "*")) + [os.path.join(ROOT, "include", "dsc_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -31,8 +47,7 @@ def build(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(HERE, "_obj", os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-               "-I" + CSRC, "-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
@@ -43,6 +58,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return OUT
 
 

@@ -41,6 +41,7 @@ struct Plan {
     hipblasLtMatmulAlgo_t cand[kMaxCand];         // the heuristic's ranking; the first call of a shape times them (tune_plan)
     int n_cand = 0;
     bool tuned = false;
+    bool cand0_failed = false;                    // the heuristic's first choice did not run when it was timed: never launch it
     size_t ws = 0;
     bool ok = false;
 };
@@ -163,6 +164,7 @@ void tune_plan(Plan& p, const void* x, const void* w, const void* residual, void
             if (good && r > 0 && ms < fastest) fastest = ms;
         }
         if (good && fastest < best) { best = fastest; p.algo = p.cand[i]; }
+        if (!good && i == 0) p.cand0_failed = true;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -216,8 +218,9 @@ extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias,
     // Which algorithm: the cold-timed fastest serves the stream that owns the chip; with several generations in flight
     // (DSC_TUNE_THROUGHPUT) the heuristic's own first choice gave +1.1 % images/s (11.57 vs 11.44; -0.8 % one at a time) -
     // the timed winners buy their latency with more workgroups / more traffic, which a shared chip pays for.
-    const hipblasLtMatmulAlgo_t* algo = (g_dsc_tuning_profile == DSC_TUNE_THROUGHPUT && plan->n_cand > 0 && lt_profile_aware())
-                                            ? &plan->cand[0] : &plan->algo;
+    // (Two library algorithms need not add in the same order: the two profiles' LIBRARY GEMMs agree to rounding, not to the bit.)
+    const hipblasLtMatmulAlgo_t* algo = (g_dsc_tuning_profile == DSC_TUNE_THROUGHPUT && plan->n_cand > 0 && !plan->cand0_failed &&
+                                         lt_profile_aware()) ? &plan->cand[0] : &plan->algo;
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, plan->desc, &alpha, w, plan->a, x, plan->b, &beta,
                                                residual ? residual : out, plan->c, out, plan->d, algo,
                                                workspace_for(), ws_bytes(), hs);

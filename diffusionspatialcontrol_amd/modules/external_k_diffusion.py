@@ -1,8 +1,8 @@
-"""eps-prediction denoiser wrappers for the k-diffusion sampling path.
+"""Denoiser wrappers for the k-diffusion sampling path: eps-prediction and v-prediction.
 
-Counterpart of reference `source/modules/external_k_diffusion.py`, eps classes only (`DiscreteSchedule` :40-83,
-`DiscreteEpsDDPMDenoiser` :86-114, `CompVisDenoiser` :132-139); the v-prediction wrappers there are not on the
-SD1.5 path.  Class and method names are the reference's so `model_k_diffusion.StableDiffusionPipeline.setup_unet`
+Counterpart of reference `source/modules/external_k_diffusion.py`: `DiscreteSchedule` (:40-83), `DiscreteEpsDDPMDenoiser`
+(:86-114), `CompVisDenoiser` (:132-139) - the SD1.5 path - and the v-prediction pair `DiscreteVDDPMDenoiser` /
+`CompVisVDenoiser` (:142-182; protocol mode only, pinned by tests/golden/vdenoiser.npz).  Class and method names are the reference's so `model_k_diffusion.StableDiffusionPipeline.setup_unet`
 (:138-146) reads the same; the implementation is the build's own:
 
   * the sigma <-> t interpolation is a binary search over the 1000-entry log-sigma table (`torch.searchsorted`)

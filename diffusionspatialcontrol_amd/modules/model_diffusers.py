@@ -221,10 +221,18 @@ class StableDiffusionPipeline_finetune(StableDiffusionPipeline):
                self._weight_func_key(weight_func), ckey)
         st = self._static_step(key, n_img, tuple(latents.shape), text, region_state, weight_func, ca_kwargs,
                                control=static_control, n_std_groups=1)
+        tab = None
+        if st["tadd"] is not None:
+            # the captured step reads the ResNets' time-embedding terms from st["tadd"] instead of running the embedding path:
+            # every timestep of this loop is known here, so their rows are computed once (UNet.temb_add_table) and row i is
+            # broadcast into the buffer before replay i.  (The buffer starts as zeros: a replay without this is timestep-blind.)
+            tab = self.unet.temb_add_table(torch.tensor([float(t) for t in ts], dtype=torch.float32, device=latents.device))
         for i, t in enumerate(ts):
             x_in = self.scheduler.scale_model_input(torch.cat([latents] * 2), t)                      # :345-346
             st["x_in"].copy_(x_in.to(text.dtype))
             st["t"].fill_(float(t))
+            if tab is not None:
+                st["tadd"].copy_(tab[i].expand_as(st["tadd"]))
             st["sigma"].fill_(float(self.scheduler.sigmas[i]))                                        # :349-354, loop index (q5)
             if control is not None:
                 keep = control["keep"][i]

@@ -1134,7 +1134,24 @@ class StableDiffusionPipeline:
 
     @staticmethod
     def _weight_func_key(weight_func):
-        return "default" if (weight_func is None or weight_func_is_default(weight_func)) else id(weight_func)
+        """"default" for anything that behaves as `w * sigma * qk.std()`; otherwise by VALUE where the callable allows it -
+        (code object, closure cell contents, defaults), so that app.py's fresh lambda per request (app.py:1004) re-uses the
+        captured step instead of paying two warm-up steps and a capture under the capture lock per request - and by object
+        identity when a captured value is not hashable (two closures of one code object may capture different values)."""
+        if weight_func is None or weight_func_is_default(weight_func):
+            return "default"
+        code = getattr(weight_func, "__code__", None)
+        if code is not None:
+            try:
+                cells = tuple(c.cell_contents for c in (getattr(weight_func, "__closure__", None) or ()))
+                key = ("wf", code, cells, getattr(weight_func, "__defaults__", None),
+                       tuple(sorted((getattr(weight_func, "__kwdefaults__", None) or {}).items())))
+                hash(key)
+                if not any(torch.is_tensor(v) for v in cells):      # tensors hash by identity and compare elementwise
+                    return key
+            except (TypeError, ValueError):                          # unhashable capture / empty cell
+                pass
+        return id(weight_func)
 
     @staticmethod
     def _slot_of(key):
@@ -1238,7 +1255,7 @@ class StableDiffusionPipeline:
         tab = None
         if st["tadd"] is not None:
             # the schedule's timesteps are known here: every step's embedding rows in one table (kept while the schedule repeats)
-            tkey = tuple(sig[:len(coeffs)])
+            tkey = (tuple(sig[:len(coeffs)]), self.unet.temb_signature())     # the schedule AND the weights the table bakes in
             if st["temb_key"] != tkey:
                 ts = [float(kdm.step_scalars(s_)[2]) for s_ in sig[:len(coeffs)]]
                 st["temb_tab"] = self.unet.temb_add_table(torch.tensor(ts, dtype=torch.float32, device=x.device))

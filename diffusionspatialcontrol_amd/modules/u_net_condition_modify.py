@@ -738,6 +738,15 @@ class _EncoderHalf:
     def temb_width(self):
         return sum(r.time_emb_proj.out_features for r in self._resnets())
 
+    def temb_signature(self):
+        """(id, in-place version) of every parameter `temb_add_table` reads - a caller that caches a table keys it by this, the
+        way `_derived` keys derived weights, so an in-place weight update or a parameter swap invalidates the cache"""
+        te = self.time_embedding
+        deps = [te.linear_1.weight, te.linear_1.bias, te.linear_2.weight, te.linear_2.bias]
+        for r in self._resnets():
+            deps += [r.time_emb_proj.weight, r.time_emb_proj.bias, r.conv1.bias]
+        return tuple((id(t), t._version) for t in deps)
+
     def temb_add_table(self, timesteps):
         """[len(timesteps), temb_width()]: row i = what `_temb_all` gives inside a forward at timestep i - for a caller that
         knows its timesteps up front (the fused denoising loop) and passes a row back as `forward(..., temb_adds=...)`.  The
@@ -815,6 +824,14 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
         self.conv_norm_out = GroupNormAct(cfg.norm_num_groups, ch[0], cfg.norm_eps, act=True)
         self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, padding=1)
 
+    def _first_block_repeats_shared_rows(self):
+        """the shared CFG prefix hands the first cross-attention n query rows against 2n key rows: only this package's own
+        processors (attention_modify._RegionProcessor) repeat the shared rows there - a user-installed processor gets the
+        full batch instead"""
+        from .attention_modify import _RegionProcessor
+        blk = self.down_blocks[0].attentions[0].transformer_blocks[0]
+        return isinstance(blk.attn1.processor, _RegionProcessor) and isinstance(blk.attn2.processor, _RegionProcessor)
+
     def _resnets(self):
         out = []
         for blk in self.down_blocks:
@@ -848,7 +865,7 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
         # again from there on (_run_down repeats the skip tensors collected so far)
         share = bool(cfg_shared_prefix) and sample.shape[0] % 2 == 0 and down_block_additional_residuals is None \
             and down_intrablock_additional_residuals is None and self.down_blocks[0].has_attn \
-            and not isinstance(encoder_hidden_states, tuple)
+            and not isinstance(encoder_hidden_states, tuple) and self._first_block_repeats_shared_rows()
         x = self._conv_in(sample[:sample.shape[0] // 2] if share else sample)
         tadd = self._temb_views(temb_adds) if temb_adds is not None else self._all_temb_adds(temb_act)
         if down_intrablock_additional_residuals is None and mid_block_additional_residual is None \

@@ -10,8 +10,8 @@ x2 upsample + conv after the first three) -> GroupNorm + SiLU -> conv_out 128->3
 absent; the oracle restatement (oracle/vae_ref.py) shares only the weights.
 
 Device work: channels-last activations; GroupNorm(+SiLU) in libdsc_hip.so (`dsc_groupnorm_silu_nhwc`), 1x1 convs as
-token-major GEMMs, 3x3 convolutions through MIOpen; the single 512-dim attention head (d > 160) goes to torch SDPA, a
-plain library call.
+token-major GEMMs, 3x3 convolutions on dsc_conv3x3_nhwc_f16; the single 512-dim attention head (d > 160: too wide for
+the flash kernel's registers) runs GEMM (scores) -> dsc_softmax_rows_f16 -> GEMM (p.v) on the hand-written kernels.
 """
 from dataclasses import dataclass
 from typing import Tuple
@@ -74,11 +74,39 @@ class VaeAttention(nn.Module):
         self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
         self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
 
+    def _hip_covers(self, t):
+        """the GEMM -> row softmax -> GEMM form takes fp16 GPU tokens whose counts fit the GEMM kernel's tiles"""
+        b, L, c = t.shape
+        return t.is_cuda and t.dtype == torch.float16 and L % 64 == 0 and c % 64 == 0 and L <= 16384
+
+    def _attend(self, q, k, vt):
+        """one image: q, k [L, c], vt = v^T [c, L] -> softmax(q k^T / sqrt(c)) v  [L, c].  The scores are materialised once
+        in fp16 (dsc_linear_f16: 'weight' = the keys), normalised in fp32 (dsc_softmax_rows_f16) and contracted with v^T as
+        the second GEMM's [N, K] operand - a 512-channel head does not fit the flash kernel's registers."""
+        scores = ops.linear(q, k, prefer_kernel=True)                                    # [L, L] = q . k^T
+        probs = ops.softmax_rows(scores, scale=q.shape[-1] ** -0.5, out=scores)         # in place: one 2 L^2-byte buffer
+        return ops.linear(probs, vt, prefer_kernel=True)                                 # [L, c] = p . v
+
     def forward(self, x):
         b, c, h, w = x.shape
         t = _tokens(self.group_norm(x))
-        q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
-        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]        # one head of dim c
+        if self._hip_covers(t):
+            q = ops.linear(t, self.to_q.weight, self.to_q.bias, prefer_kernel=True)
+            k = ops.linear(t, self.to_k.weight, self.to_k.bias, prefer_kernel=True)
+            L = h * w
+            # v^T [c, L] straight from a GEMM with the roles swapped (x = W_v, 'weight' = the tokens); its bias is a ROW
+            # constant there, so it rides as the GEMM's residual operand (a [c, L] expansion of b_v, cached per L)
+            from .u_net_condition_modify import _derived
+            bcol = _derived(self, f"vbias_{L}", (self.to_v.bias,),
+                            lambda: self.to_v.bias.detach()[:, None].expand(c, L).contiguous())
+            outs = []
+            for i in range(b):
+                vt = ops.linear(self.to_v.weight, t[i], residual=bcol, prefer_kernel=True)
+                outs.append(self._attend(q[i], k[i], vt))
+            o = outs[0][None] if b == 1 else torch.stack(outs)
+        else:
+            q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
+            o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]    # one head of dim c (library call)
         return _image(ops.linear(o, self.to_out[0].weight, self.to_out[0].bias, residual=_tokens(x)), h, w)
 
 

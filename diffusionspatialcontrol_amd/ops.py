@@ -47,7 +47,9 @@ TUNING_PROFILES = {"latency": 0, "throughput": 1}       # DSC_TUNE_LATENCY / DSC
 def set_tuning_profile(name):
     """launch rules for one generation at a time ("latency", the default) or for several generations in flight on their
     own streams ("throughput") - dsc_set_tuning_profile.  Read at launch time: a step graph keeps the profile it was
-    captured under, and the pipeline re-captures a slot's step when the profile has changed since."""
+    captured under, and the pipeline re-captures a slot's step when the profile has changed since.  The package's own kernels
+    give equal bytes under both; a GEMM left to the library (dsc_linear_lt_f16) may run another library algorithm and then
+    agrees to rounding only."""
     if name not in TUNING_PROFILES:
         raise ValueError(f"tuning profile must be one of {sorted(TUNING_PROFILES)}")
     _lib.check(_lib.load_library().dsc_set_tuning_profile(TUNING_PROFILES[name]), "dsc_set_tuning_profile")
@@ -459,8 +461,9 @@ def linear_qkv(x, weight, bias, heads, ln=None):
     return q.view(B, L, heads, d), kv[0].permute(0, 2, 1, 3), kv[1].permute(0, 2, 1, 3)
 
 
-def linear(x, weight, bias=None, residual=None, geglu=False):
+def linear(x, weight, bias=None, residual=None, geglu=False, prefer_kernel=False):
     """x @ weight.T (+ bias) (+ residual), or the fused GEGLU of [x @ weight.T + bias]; x [..., K], weight [N, K].
+    prefer_kernel: take the hand-written GEMM whenever it CAN run the shape, whatever the row / K thresholds say.
 
     Shapes the hand-written MFMA kernel covers (fp16, K % 64 == 0, N % 64 == 0, >= DSC_GEMM_MIN_ROWS rows, unit inner
     stride) go to dsc_linear_f16 with the epilogue fused; everything else is a plain library GEMM through torch
@@ -482,7 +485,7 @@ def linear(x, weight, bias=None, residual=None, geglu=False):
     if can and residual is not None:
         r2 = residual.reshape(M, N)
         can = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
-    ok = can and _gemm_rows_k_preferred(M, K, geglu)
+    ok = can and (prefer_kernel or _gemm_rows_k_preferred(M, K, geglu))
     if not ok:
         if ((USE_LT_RESIDUAL if residual is not None else USE_LT_ALL) and x.dtype == torch.float16 and K % 8 == 0
                 and N % 8 == 0 and M >= 8 and not (geglu and residual is not None)):
@@ -642,6 +645,20 @@ def add_layernorm(x, a, weight, bias, eps=1e-5):
                                                rows, C, float(eps), 0, _stream_ptr(x))
     _lib.check(rc, "dsc_add_layernorm")
     return s, y
+
+
+def softmax_rows(scores, scale=1.0, out=None):
+    """softmax(scale * scores, dim=-1) of an fp16 [rows, n] matrix (unit inner stride, 16-byte aligned rows) in fp32 arithmetic
+    (dsc_softmax_rows_f16) - the middle step of the VAE's 512-channel attention head between its two GEMMs."""
+    _require_gpu(scores)
+    if scores.dtype != torch.float16 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise TypeError("softmax_rows: a 2-D fp16 matrix with unit inner stride")
+    if out is None:
+        out = torch.empty_like(scores)
+    rc = _lib.load_library().dsc_softmax_rows_f16(_p(scores), _p(out), scores.shape[0], scores.shape[1], scores.stride(0),
+                                                  out.stride(0), float(scale), 0, _stream_ptr(scores))
+    _lib.check(rc, "dsc_softmax_rows_f16")
+    return out
 
 
 def geglu(x):

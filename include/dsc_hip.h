@@ -351,7 +351,10 @@ int dsc_set_workspace_slot(int slot);
  *   DSC_TUNE_THROUGHPUT  several generations share the chip on their own streams: the three-stage ring / four-wave forms,
  *                        which leave room for the other stream's workgroups on the same CU.  +3 % images/s with two generations
  *                        in flight against the latency rules (7 interleaved runs each on one box: 10.81 vs 10.46).
- * The two give equal bytes.  Returns DSC_ERR_BAD_ARG for any other value.
+ * This library's OWN kernels give equal bytes under the two (tests/...::test_conv3x3_and_gemm_profiles_give_equal_bytes); a GEMM
+ * that is left to hipBLASLt (dsc_linear_lt_f16) may run another library algorithm under DSC_TUNE_THROUGHPUT, and two library
+ * algorithms need not add in the same order: those results agree to rounding, not to the bit.
+ * Returns DSC_ERR_BAD_ARG for any other value.
  */
 #define DSC_TUNE_LATENCY 0
 #define DSC_TUNE_THROUGHPUT 1
@@ -386,6 +389,16 @@ int dsc_add_layernorm(const void* x, const void* a, const void* gamma, const voi
 /* GEGLU of the transformer feed-forward (diffusers GEGLU): y[r, j] = x[r, j] * gelu(x[r, n + j]), exact erf gelu.
  * x fp16 [rows, 2n] contiguous, y fp16 [rows, n]; n % 8 == 0. */
 int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);
+
+/*
+ * Row softmax of materialised fp16 scores: probs[r, :] = softmax(scale * scores[r, :]), fp32 arithmetic, one fp16 rounding.
+ * The middle step of the VAE decoder's / encoder's single 512-channel attention head (diffusers AutoencoderKL mid-block
+ * `Attention`, reached from modules/model_k_diffusion.py:291-299 `decode_latents` and :600-606 `vae.encode`): too wide for
+ * the flash kernel's registers, so it runs scores = q.k^T (dsc_linear_f16) -> this -> out = probs.v (dsc_linear_f16).
+ * rows x n fp16, row strides ld_* in elements (% 8 == 0); n % 8 == 0, n <= 16384.  One workgroup per row, one launch.
+ */
+int dsc_softmax_rows_f16(const void* scores, void* probs, int64_t rows, int n, int64_t ld_scores, int64_t ld_probs,
+                         float scale, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -437,3 +437,100 @@ def test_shared_cfg_prefix_equals_the_full_batch(sd15):
         # two fp16 evaluations of the same function through different launch geometries: ~half an fp16 ulp of the output on average
         assert err.max().item() < 4e-3 * scale and err.mean().item() < 6e-4 * scale, (n, err.max().item(), err.mean().item(), scale)
         assert (shared.float() - full.float()).abs().max().item() > 0 or n == 0      # (not the same launches: a real second path)
+
+
+# ------------------------------------------------------------------ end-to-end: all 25 steps, the north star's stated tolerance
+# Observed on MI355X (round 3; printed by the test): see DESIGN.md section 2 for the numbers these bounds were derived from.
+FINAL_LATENT_TOL_MAX = 1.5e-2          # max |final latent - oracle| / oracle range, after 25 DPM++ 2M Karras steps
+FINAL_LATENT_TOL_MEAN = 2.0e-3         # mean |...| / range
+
+
+@pytest.mark.parametrize("profile", ["latency", "throughput"])
+def test_sd15_25_step_loop_full_size_vs_oracle(sd15, profile):
+    """configs[1] END TO END: all 25 DPM++ 2M Karras steps at 512x512, 2 region masks, seed-1000 latent, through `txt2img`'s
+    fused loop (captured UNet step + dsc_cfg_dpmpp2m_step) under BOTH launch-rule profiles, final latents vs the fp32 CPU
+    oracle loop (oracle/unet_ref.denoise_loop; the value reference `sampler(model_fn, latents, ...)` returns,
+    model_k_diffusion.py:1175).  The bound is the north star's "stated fp16 tolerance" (DESIGN.md section 2)."""
+    from diffusionspatialcontrol_amd import ops
+    emb, ids, state, _ = _inputs(512, 2)
+    rs = _region_tables(sd15.pipe, state, 512, ids)
+    sig = sd15.pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
+    lat = _latent(0)[None]
+    text = torch.cat([emb[0:1], emb[1:2]])
+    ref = _oracle_final_latents(sd15, lat, sig, text, rs)
+    try:
+        ops.set_tuning_profile(profile)
+        got = _fused(sd15, lat, sig, text, rs, 25)
+    finally:
+        ops.set_tuning_profile("latency")
+    assert torch.isfinite(got).all()
+    scale = ref.abs().max().item()
+    err = (got - ref).abs()
+    print(f"25-step loop [{profile}]: max {err.max().item():.3e} mean {err.mean().item():.3e} range {scale:.3f} "
+          f"(max/range {err.max().item() / scale:.2e}, mean/range {err.mean().item() / scale:.2e})")
+    assert err.max().item() < FINAL_LATENT_TOL_MAX * scale, (err.max().item(), scale)
+    assert err.mean().item() < FINAL_LATENT_TOL_MEAN * scale, (err.mean().item(), scale)
+
+
+_ORACLE_25 = {}
+
+
+def _oracle_final_latents(sd15, lat, sig, text, rs):
+    """the oracle's 25-step latents, computed once per session (~2 min of CPU) and shared by the two profile cases"""
+    if "ref" not in _ORACLE_25:
+        _ORACLE_25["ref"] = _oracle_loop(sd15, lat.half(), sig, text.half(), rs, 25)
+    return _ORACLE_25["ref"]
+
+
+def test_sd15_768_forward_full_size_vs_oracle(sd15):
+    """configs[3] geometry, one CFG UNet forward at 768x768 (L = 9216 / 2304 / 576 / 144; the 12x12 level runs the ragged
+    convolution tiles) vs the fp32 oracle on shared weights.  Same bound as the 512x512 forward: 4e-3 of range, 5e-4 mean."""
+    emb, ids, state, _ = _inputs(768, 2)
+    rs = _region_tables(sd15.pipe, state, 768, ids)
+    x = torch.stack([_latent(0, 96), _latent(0, 96)]).half()
+    t = torch.tensor([540.5, 540.5])
+    text = emb.half()
+    rp = {"region_state": rs, "sigma": torch.tensor([2.5], device="cuda"), "weight_func": lambda w, s, qk: w * s * qk.std()}
+    with torch.no_grad():
+        out = sd15.unet(x.cuda(), t.cuda(), text.cuda(), cross_attention_kwargs={"region_prompt": rp}).sample.float().cpu()
+    ref = unet_ref.unet_forward(sd15.sd, sd15.cfg, x.float(), t, text.float(),
+                                region_prompt={"region_state": rs, "sigma": 2.5, "weight_func": None})
+    scale = ref.abs().max().item()
+    err = (out - ref).abs()
+    print(f"768x768 forward: max {err.max().item():.3e} mean {err.mean().item():.3e} range {scale:.3f}")
+    assert err.max().item() < 4e-3 * scale, (err.max().item(), scale)
+    assert err.mean().item() < 5e-4 * scale, (err.mean().item(), scale)
+
+
+def test_vae_decode_full_size_vs_oracle():
+    """SURVEY 8f rank 1 at the SD1.x geometry: 64x64 latent -> 512x512 RGB through the production kernels (conv3x3, GroupNorm,
+    1x1 GEMMs, and the single 512-dim attention head over 4096 tokens on the HIP path: gemm_tn scores -> dsc_softmax_rows ->
+    gemm_tn P.V) vs the fp32 oracle (oracle/vae_ref.py; reference model_k_diffusion.py:291-299) on shared weights.
+    Bound 1.5e-2 of the output range (max), 2e-3 (mean) - the toy-width test's bound."""
+    from diffusionspatialcontrol_amd.modules.vae_decoder import AutoencoderKLDecoder
+    from oracle import vae_ref
+    torch.manual_seed(5)
+    vae = AutoencoderKLDecoder().half().eval()
+    sd = {k: v.clone() for k, v in vae.state_dict().items()}
+    vae = vae.cuda()
+    z = (torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(11)) * 0.9).half()
+    seen = {}
+    import diffusionspatialcontrol_amd.modules.vae_decoder as vd
+    orig = vd.VaeAttention._attend
+    def spy(self, q, k, vt):
+        seen["hip"] = True
+        return orig(self, q, k, vt)
+    vd.VaeAttention._attend = spy
+    try:
+        with torch.no_grad():
+            out = vae.decode(z.cuda()).sample.float().cpu()
+    finally:
+        vd.VaeAttention._attend = orig
+    assert seen.get("hip"), "the VAE attention did not take the HIP path"
+    with torch.no_grad():
+        ref = vae_ref.vae_decode(sd, z.float())
+    assert out.shape == (1, 3, 512, 512)
+    scale = ref.abs().max().item()
+    err = (out - ref).abs()
+    print(f"VAE decode 64x64 -> 512x512: max {err.max().item():.3e} mean {err.mean().item():.3e} range {scale:.3f}")
+    assert err.max().item() < 1.5e-2 * scale and err.mean().item() < 2e-3 * scale, (err.max().item(), err.mean().item(), scale)

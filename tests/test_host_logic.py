@@ -617,3 +617,20 @@ def test_bench_refuses_a_gpus_world_size_mismatch_and_self_launches():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0                          # both ranks exit with "bench.py needs an MI355X"
     assert "needs an MI355X" in (r.stderr + r.stdout)
+
+
+def test_weight_func_key_is_by_value_where_the_callable_allows():
+    """a fresh lambda per request (reference app.py:1004) must not force a re-capture: equal code + equal captured values ->
+    equal key; different captured values -> different keys; unhashable captures -> object identity"""
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import StableDiffusionPipeline as P
+
+    def make(c):
+        return lambda w, s, qk: w * s * c * qk.std()
+
+    assert P._weight_func_key(None) == "default"
+    assert P._weight_func_key(lambda w, s, qk: w * s * qk.std()) == "default"
+    assert P._weight_func_key(make(2.0)) == P._weight_func_key(make(2.0))
+    assert P._weight_func_key(make(2.0)) != P._weight_func_key(make(3.0))
+    box = [2.0]
+    f1, f2 = (lambda w, s, qk: w * s * box[0] * qk.std()), (lambda w, s, qk: w * s * box[0] * qk.std())
+    assert P._weight_func_key(f1) == id(f1) and P._weight_func_key(f2) == id(f2)        # a list cell: by identity
