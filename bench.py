@@ -335,6 +335,10 @@ def main():
         else:
             td.init_process_group(backend)
 
+    if dist:
+        # ranks must run the SAME kernels on the same image (per-image equality across ranks): a GEMM that is
+        # left to hipBLASLt takes the heuristic's first algorithm instead of the per-process cold-timed one (linear_lt.hip)
+        os.environ.setdefault("DSC_LT_TUNE", "1")
     from diffusionspatialcontrol_amd import ops
     from diffusionspatialcontrol_amd.modules.model_k_diffusion import SD15Scheduler, StableDiffusionPipeline
     from diffusionspatialcontrol_amd.modules.u_net_condition_modify import UNet2DConditionModel, UNetConfig
@@ -472,12 +476,27 @@ def main():
             res["cpu_baseline"]["gpu_vs_cpu_on_the_sample"] = {
                 "max_abs_err": round(err.max().item(), 5), "mean_abs_err": round(err.mean().item(), 6),
                 "ref_max_abs": round(ref.abs().max().item(), 4), "note": "latents after the sampled steps: fp16 HIP path vs fp32 oracle"}
+    # self-describing multi-GPU lines: what each rank ran on
+    me = f"{torch.cuda.get_device_name(dev)} (cuda:{local} of {torch.cuda.device_count()} visible)"
+    if dist:
+        names = [None] * world
+        td.all_gather_object(names, me)
+    else:
+        names = [me]
+    if res is not None:
+        res["config"]["devices"] = names
     if nfl > 1:
         # the launch rules for generations that SHARE the chip (include/dsc_hip.h, dsc_set_tuning_profile): the legs above ran
         # under "latency"; every slot re-captures its step under "throughput" here, outside the timed region
         ref_same_rules = out
         if a.tuning_profile == "auto":
             ops.set_tuning_profile("throughput")
+            if res is not None and "cpu_baseline" in res:
+                # the headline leg's launch rules against the oracle too (the check above ran under the latency rules)
+                got = gpu_sample(pipe, sig.to(dev), text.to(dev), rs, lat[:1], 7.5, a.cpu_sample_steps).float().cpu()
+                err = (got - ref).abs()
+                res["cpu_baseline"]["gpu_vs_cpu_on_the_sample_throughput_profile"] = {
+                    "max_abs_err": round(err.max().item(), 5), "mean_abs_err": round(err.mean().item(), 6)}
             for s_i, st in enumerate(streams):
                 with torch.cuda.stream(st):
                     o_ = generate(s_i)
