@@ -49,7 +49,7 @@ __device__ __forceinline__ void scores(const XattnParams& p, const half_t* Ks, c
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             // attention_modify.py:90 - the matmul result is an fp16 tensor, then * scale_factor rounds again
-            if (REF16) acc[m][i] = round_f16(round_f16(acc[m][i]) * scale);
+            if (REF16) acc[m][i] = round_f16(pin_f32(round_f16(acc[m][i]) * scale));
             else if (!RAW) acc[m][i] = acc[m][i] * scale;
         }
     }

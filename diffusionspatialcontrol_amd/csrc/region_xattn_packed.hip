@@ -78,21 +78,21 @@ __device__ __forceinline__ void dma_image(const half_t* src, char* lds, int piec
 template <int NK, bool REF16, bool RAW = false>
 __device__ __forceinline__ void scores_img(const XattnParams& p, const half_t* img, const h8_t (&qf)[NK], f16x_t (&acc)[3],
                                            int lane, float scale) {
-    const int mt = (p.S + 31) >> 5;
+    // all three 32-key tiles, no branch on the key count: the image holds ZERO fragments beyond S (xp_pack), so a tile past the
+    // last key costs three MFMAs on zeros and its scores are masked anyway - while a wave-uniform `if (m < mt)` around each
+    // tile made every fragment read wait for its own s_waitcnt in front of its MFMA (one LDS latency exposed per MFMA)
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-        if (m < mt) {
 #pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const h8_t kf = *reinterpret_cast<const h8_t*>(img + ((m * NK + ks) * 64 + lane) * 8);
-                acc[m] = mfma_32x32x16(kf, qf[ks], acc[m]);
-            }
+        for (int ks = 0; ks < NK; ++ks) {
+            const h8_t kf = *reinterpret_cast<const h8_t*>(img + ((m * NK + ks) * 64 + lane) * 8);
+            acc[m] = mfma_32x32x16(kf, qf[ks], acc[m]);
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            if (REF16) acc[m][i] = round_f16(round_f16(acc[m][i]) * scale);   // attention_modify.py:90
+            if (REF16) acc[m][i] = round_f16(pin_f32(round_f16(acc[m][i]) * scale));   // attention_modify.py:90
             else if (!RAW) acc[m][i] = acc[m][i] * scale;
         }
     }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
 // diagnostic stamps (flag 32): shader-clock and 100 MHz real-time stamps of workgroup 0 go to x.std_out (never an
 // output tensor); no stamp executes in a normal call
 #define XP_STAMP(n)                                                                                          \
-    if (dbg) {                                                                                               \
+    if constexpr (STAMPS) if (dbg) {                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime(), r_ = __builtin_amdgcn_s_memrealtime();   \
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                                  \
@@ -161,7 +161,9 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
     }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int NK, bool REF16>
+// STAMPS: the diagnostic instantiation (debug flag 32, tools/stamps_xattn.py); the stamps' scheduling barriers and branches cut
+// the kernel into blocks the compiler cannot overlap, so the production instantiation carries none of them
+template <int NK, bool REF16, bool STAMPS = false>
 __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams pp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using P = PCfg<NK>;
@@ -175,9 +177,9 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
     const bool has_bias = pp.ids != nullptr;
     const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;   // repeat_interleave, :96-99
-    const int mt = (p.S + 31) >> 5, nt = (p.S + 15) >> 4;
-    const bool dbg = (p.flags & 32u) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && p.std_out != nullptr;
+    const bool dbg = STAMPS && (p.flags & 32u) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && p.std_out != nullptr;
     unsigned long long* dbgp = reinterpret_cast<unsigned long long*>(p.std_out) + wave * 64;
+    (void)dbg; (void)dbgp;
     XP_STAMP(0)
 
     // ---- prologue: image DMA, first tile's Q / row id, std partials - all in flight together
@@ -192,33 +194,39 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
         if (has_bias) id = pp.ids[(long long)bw * p.L + row];
     }
     float sd = 1.f, sig = 1.f;
-    constexpr int kRowRegs = (kNUMax * kBP + kThreads - 1) / kThreads;      // 13: the whole table in flight at once
-    float rowv[kRowRegs];
+    // distinct rows -> LDS: thread t owns key column t % 128 of rows t / 128, t / 128 + 2, ... - ONE lane mask (s < S) for all
+    // sixteen loads and a wave-uniform row test, instead of thirteen (row, column) masks that the compiler kept in (spilled)
+    // SGPRs between the loads and the stores.  Columns [S, kBP) of the table stay unwritten: a score that reads them is beyond
+    // the last key and is replaced by -inf with a select, never used in arithmetic.
+    constexpr int kRowRegs = kNUMax / 2;
     if (has_bias) {
+        float rowv[kRowRegs];
+        const int bs = threadIdx.x & 127, bu = threadIdx.x >> 7;
 #pragma unroll
         for (int c = 0; c < kRowRegs; ++c) {
-            const int idx = threadIdx.x + c * kThreads, u = idx / kBP, s = idx - u * kBP;
-            rowv[c] = (idx < pp.NU * kBP && s < p.S) ? pp.rows[u * p.S + s] : 0.f;
+            const int u = bu + 2 * c;
+            rowv[c] = 0.f;
+            if (u < pp.NU && bs < p.S) rowv[c] = pp.rows[u * p.S + bs];
         }
         XP_STAMP(7)
         double a1, a2;
         group_partials(p, b % p.n_groups, a1, a2);
         sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
-        if (dbg) { asm volatile("" :: "v"(a1), "v"(a2), "v"(sig)); }
         XP_STAMP(8)
-        sd = group_std_finish(p, a1, a2, red, REF16);        // contains a __syncthreads()
-        XP_STAMP(9)
 #pragma unroll
-        for (int c = 0; c < kRowRegs; ++c) {                     // columns [S, kBP) are zero padding for the b128 reads
-            const int idx = threadIdx.x + c * kThreads;
-            if (idx < pp.NU * kBP) biasT[idx] = (rowv[c] * sig) * sd;         // w * sigma * std, fp32 (app.py:1004)
+        for (int c = 0; c < kRowRegs; ++c) {
+            const int u = bu + 2 * c;
+            if (u < pp.NU && bs < p.S) biasT[u * kBP + bs] = rowv[c];
         }
+        group_std_stage(a1, a2, red);
+        XP_STAMP(9)
     }
     XP_STAMP(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA'd image has landed (this wave's pieces)
     XP_STAMP(2)
-    __syncthreads();                                         // ... and everyone else's; bias table complete
+    __syncthreads();                                         // ... and everyone else's; raw rows and partial pairs are in LDS
     XP_STAMP(3)
+    if (has_bias) sd = group_std_reduce(p, red, REF16);      // per wave, no barrier: overlaps the first tile's score MFMAs
 
     for (int t = 0; t < p.tiles_per_wave; ++t) {
         // prefetch the next tile's Q fragments / row id behind this tile's MFMAs
@@ -241,33 +249,31 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
             h8_t pf[6];
             float oscale = 1.f;
             const float* brow = has_bias ? biasT + id * kBP : nullptr;
-            if (REF16) softmax_tile<REF16, true>(acc, pf, brow, 1.f, 1.f, p.S, hh);
-            else oscale = softmax_tile_lean<true>(acc, pf, brow, 1.f, 1.f, p.scale * 1.4426950408889634f, p.S, hh);
+            if (REF16) softmax_tile<REF16, true>(acc, pf, brow, sig, sd, p.S, hh);          // bias = (w * sigma) * std, fp32 (app.py:1004)
+            else oscale = softmax_tile_lean<true>(acc, pf, brow, sig, sd, p.scale * 1.4426950408889634f, p.S, hh);
 
             XP_STAMP(5)
             half_t* ob = p.out + b * p.osb + h * p.osh + (long long)row * p.osl;
             const bool row_ok = l0 + r < p.L;
+            // every channel tile (32 dm < d holds for the NK that pick_nk gives d) and all six 16-key steps, no branch: V^T
+            // fragments beyond S are zeros in the image and so are the probabilities of masked keys
 #pragma unroll
             for (int dm = 0; dm < DM; ++dm) {
-                if (32 * dm < p.d) {
-                    f16x_t o;
+                f16x_t o;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+                for (int i = 0; i < 16; ++i) o[i] = 0.f;
 #pragma unroll
-                    for (int tt = 0; tt < 6; ++tt) {
-                        if (tt < nt) {
-                            const h8_t vf = *reinterpret_cast<const h8_t*>(img + ((P::KFR + dm * 6 + tt) * 64 + lane) * 8);
-                            o = mfma_32x32x16(vf, pf[tt], o);
-                        }
-                    }
+                for (int tt = 0; tt < 6; ++tt) {
+                    const h8_t vf = *reinterpret_cast<const h8_t*>(img + ((P::KFR + dm * 6 + tt) * 64 + lane) * 8);
+                    o = mfma_32x32x16(vf, pf[tt], o);
+                }
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
-                        if (row_ok && dd0 < p.d) {
-                            const h4_t ov = {(half_t)(o[4 * g4] * oscale), (half_t)(o[4 * g4 + 1] * oscale),
-                                             (half_t)(o[4 * g4 + 2] * oscale), (half_t)(o[4 * g4 + 3] * oscale)};
-                            *reinterpret_cast<h4_t*>(ob + dd0) = ov;
-                        }
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
+                    if (row_ok && dd0 < p.d) {
+                        const h4_t ov = {(half_t)(o[4 * g4] * oscale), (half_t)(o[4 * g4 + 1] * oscale),
+                                         (half_t)(o[4 * g4 + 2] * oscale), (half_t)(o[4 * g4 + 3] * oscale)};
+                        *reinterpret_cast<h4_t*>(ob + dd0) = ov;
                     }
                 }
             }
@@ -529,6 +535,14 @@ int launch_packed(const XpParams& pp, bool need_stats, hipStream_t st) {
     if (need_stats)
         DSC_LAUNCH((xp_stats<NK, REF16>), grid, block, (size_t)P::KFR * 1024 + kRedBytes, st, pp);
     const size_t lds = (size_t)P::IMG * 2 + (size_t)kNUMax * kBP * 4 + kRedBytes;
+    if constexpr (!REF16 && (NK == 3 || NK == 10)) {           // the diagnostic instantiation (tools/stamps_xattn.py's two shapes)
+        if (pp.x.flags & 32u) {
+            static bool sattr = false;
+            if (!sattr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&xp_fwd<NK, REF16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); sattr = true; }
+            DSC_LAUNCH((xp_fwd<NK, REF16, true>), grid, block, lds, st, pp);
+            return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+        }
+    }
     DSC_LAUNCH((xp_fwd<NK, REF16>), grid, block, lds, st, pp);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include "dsc_common.h"
 #include "dsc_hip.h"
+#include <type_traits>
 
 namespace dsc_xattn {
 
@@ -26,6 +27,7 @@ struct XattnParams {
     // additive attention mask of the statistics pass (dsc_region_xattn_std_masked; reference attention_modify.py:85-95:
     // the std is taken over scale * q.k^T + mask): fp32, element (bh, l, s) at mask[bh * msbh + l * msl + s]; strides 0 = broadcast
     const float* mask; long long msbh, msl;
+    double inv_n, inv_nm1;       // 1 / n and 1 / (n - 1), n = scores per std group (plan_tiles)
 };
 
 // grid = (8, H, Bc*nchunks/8) when Bc*nchunks % 8 == 0, else (1, H, Bc*nchunks).  The hardware deals linear workgroup
@@ -121,31 +123,51 @@ __device__ __forceinline__ void load_q_frags(const XattnParams& p, h8_t (&qf)[NK
 __device__ __forceinline__ void group_partials(const XattnParams& p, int g, double& a1, double& a2) {
     const double* src = p.partials + (long long)g * p.npart * 2;
     a1 = 0.0; a2 = 0.0;
-    for (int i = threadIdx.x; i < p.npart; i += kThreads) { a1 += src[2 * i]; a2 += src[2 * i + 1]; }
+    // pairs threadIdx.x, threadIdx.x + 256, ... added in that order; the loads go out four at a time (a loop of load - wait -
+    // add made every pair a memory round trip of its own: the partials come from the other XCDs' workgroups of the statistics
+    // launch, i.e. from beyond this XCD's L2)
+    constexpr int kPL = 4;
+    for (int i0 = threadIdx.x; i0 < p.npart; i0 += kPL * kThreads) {
+        double v1[kPL], v2[kPL];
+#pragma unroll
+        for (int u = 0; u < kPL; ++u) {
+            const int i = i0 + u * kThreads;
+            v1[u] = 0.0; v2[u] = 0.0;
+            if (i < p.npart) { v1[u] = src[2 * i]; v2[u] = src[2 * i + 1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kPL; ++u) { a1 += v1[u]; a2 += v2[u]; }     // (+ 0.0 for the pairs past the end: exact)
+    }
 }
-// `red` needs 2 * kThreads doubles of LDS.  Tree through LDS instead of 12 dependent ds_bpermute shuffles of doubles:
-// every thread stores its pair, 8 threads each add 32 pairs in a fixed order, then everyone adds those 8.
-__device__ __forceinline__ float group_std_finish(const XattnParams& p, double a1, double a2, double* red, bool ref16) {
+// `red` needs 2 * kThreads doubles of LDS, 16-byte aligned.  Two halves around ONE workgroup barrier (which a kernel can share
+// with the barrier that publishes its LDS images): every thread stores its pair; after the barrier each WAVE adds all 256 pairs
+// itself - lane i the pairs i, i + 64, i + 128, i + 192 in that order, then a fixed xor butterfly - so every lane of every wave
+// of every workgroup holds the same bits, with no second barrier and no single-thread tail.  (Round 2: 256 -> 16 -> 1 through
+// LDS with two barriers, the second one exposed in front of the softmax of every workgroup.)
+__device__ __forceinline__ void group_std_stage(double a1, double a2, double* red) {
     red[2 * threadIdx.x] = a1;
     red[2 * threadIdx.x + 1] = a2;
-    __syncthreads();
-    double* red2 = red + 2 * kThreads;                       // 256 -> 16 (each of 16 threads adds 16 pairs) -> all add 16
-    if (threadIdx.x < 16) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < kThreads / 16; ++i) { s1 += red[2 * (threadIdx.x * 16 + i)]; s2 += red[2 * (threadIdx.x * 16 + i) + 1]; }
-        red2[2 * threadIdx.x] = s1; red2[2 * threadIdx.x + 1] = s2;
-    }
-    __syncthreads();
+}
+__device__ __forceinline__ float group_std_reduce(const XattnParams& p, const double* red, bool ref16) {
+    const int lane = threadIdx.x & 63;
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { t1 += red2[2 * w]; t2 += red2[2 * w + 1]; }
-    const double n = (double)(p.Bc / p.n_groups) * p.H * (double)p.L * p.S;
-    double var = (t2 - t1 * t1 / n) / (n - 1.0);             // unbiased, torch.std default
+    for (int w = 0; w < kThreads / 64; ++w) { t1 += red[2 * (lane + 64 * w)]; t2 += red[2 * (lane + 64 * w) + 1]; }
+    t1 = wave_sum_f64(t1);                                   // xor butterfly: commutative pair sums, the same bits in every lane
+    t2 = wave_sum_f64(t2);
+    // unbiased variance (torch.std default) with the two reciprocals from the host (fp64 divides are ~30-instruction
+    // sequences and this runs in every wave of every workgroup), the cancellation-prone subtraction still in fp64; the square
+    // root in fp32 (the oracle's std is an fp32 tensor: one more rounding at 6e-8)
+    double var = (t2 - t1 * t1 * p.inv_n) * p.inv_nm1;
     var = var > 0.0 ? var : 0.0;
-    float sd = (float)sqrt(var);
+    float sd = sqrtf((float)var);
     if (ref16) sd = round_f16(sd);                           // std of an fp16 tensor is a 0-dim fp16 tensor
     return sd;
+}
+__device__ __forceinline__ float group_std_finish(const XattnParams& p, double a1, double a2, double* red, bool ref16) {
+    group_std_stage(a1, a2, red);
+    __syncthreads();
+    return group_std_reduce(p, red, ref16);
 }
 __device__ __forceinline__ float group_std(const XattnParams& p, int g, double* red, bool ref16) {
     double a1, a2;
@@ -153,6 +175,9 @@ __device__ __forceinline__ float group_std(const XattnParams& p, int g, double* 
     return group_std_finish(p, a1, a2, red, ref16);
 }
 
+
+// an fp32 value the compiler must materialise as computed: no contraction into the consumer (emulation mode only)
+__device__ __forceinline__ float pin_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 
 // Bias of the 4 consecutive keys 32m + 8g + 4hh + {0..3} of this lane's row.  VEC: the row lives in LDS with a
 // 16-byte-aligned base and zero padding up to key 99 (packed kernel: one ds_read_b128); else scalar, address clamped.
@@ -167,6 +192,9 @@ __device__ __forceinline__ void bias4(const float* brow, int s0, int smax, float
     }
 }
 
+// (Emulation mode pins every fp32 result that is rounded to fp16 next, or feeds an add, with pin_f32: left to the compiler,
+// `(half)(a * b)` and `a + b * c` become a v_fma_mix / fma with ONE rounding in some instantiations and two operations in
+// others - one-ulp differences between kernels that are meant to give the same bits.  __fmul_rn does not prevent it.)
 // Biased softmax of one 32-row score tile, branch-free.  acc[m][i] holds score (key s = 32m + (i&3) + 8(i>>2) + 4hh,
 // query row = lane & 31) on entry; on exit pf[] holds the fp16 probabilities packed as the B operand of the PV MFMA.
 // brow: this lane's bias row in LDS (nullptr = no bias, wave-uniform); bias = (brow[s] * mul1) * mul2 (mul1 = sigma,
@@ -187,7 +215,9 @@ __device__ __forceinline__ void softmax_tile(f16x_t (&acc)[3], h8_t (&pf)[6], co
                 const int i = 4 * g + j, s = 32 * m + 8 * g + 4 * hh + j;
                 float a = acc[m][i];
                 if (brow) {
-                    a = a + (bias[j] * mul1) * mul2;                // w * sigma * std, fp32 (app.py:1004, :97)
+                    // w * sigma * std, then the add: three separately rounded fp32 operations, as the reference's tensors are
+                    // (app.py:1004, :97) - never contracted into an fma, so every instantiation gives the same bits
+                    a = pin_f32(a + pin_f32(pin_f32(bias[j] * mul1) * mul2));
                     if (REF16) a = round_f16(a);
                 }
                 a = s < S ? a : -INFINITY;                          // select, not a branch
@@ -210,22 +240,22 @@ __device__ __forceinline__ void softmax_tile(f16x_t (&acc)[3], h8_t (&pf)[6], co
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)(acc[m][i] * inv);   // fp16 tensor (:101)
+        for (int i = 0; i < 16; ++i) pf[2 * m + (i >> 3)][i & 7] = (half_t)pin_f32(acc[m][i] * inv);   // fp16 tensor (:101)
 }
 
-// Lean variant for fp32 scores (no fp16-rounding emulation): acc holds the RAW q.k products.  Works in base 2:
-// a2 = acc * (scale*log2e) + bias2, p = exp2(a2 - max) left UNNORMALISED in pf (values <= 1);
-// the caller multiplies the 16 PV outputs per channel tile by the returned 1/sum instead of 48 probabilities.
-// bias2 = ((brow[s] * mul1) * mul2) * log2e.
+// Lean variant for fp32 scores (no fp16-rounding emulation): acc holds the RAW q.k products and they STAY raw through the
+// maximum - the bias is brought into raw-score units instead (bias * sigma * std / scale: ONE fma per score), and the softmax
+// scale rides in the exponent's fma: p = exp2(a' * c - max(a') * c), c = scale * log2 e.  Per score: fma, max, fma, exp, add
+// (round 2: two multiplies, fma, compare + select, max, subtract, exp, add).  The key mask (s < S) is applied only in the
+// 32-key tile that S actually cuts (wave-uniform test per tile).  p is left UNNORMALISED in pf (values <= 1); the caller
+// multiplies the 16 PV outputs per channel tile by the returned 1/sum instead of 48 probabilities.
 template <bool VEC>
 __device__ __forceinline__ float softmax_tile_lean(f16x_t (&acc)[3], h8_t (&pf)[6], const float* brow, float mul1,
                                                    float mul2, float scale_log2e, int S, int hh) {
-    constexpr float kLog2e = 1.4426950408889634f;
     const int smax = S - 1;
-    const float mm = mul2 * kLog2e;
+    const float bmul = (mul1 * mul2) * (1.4426950408889634f / scale_log2e);     // sigma * std / scale
     float mx = -INFINITY;
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
+    auto pass1 = [&](int m, auto masked) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float bias[4] = {0.f, 0.f, 0.f, 0.f};
@@ -233,20 +263,27 @@ __device__ __forceinline__ float softmax_tile_lean(f16x_t (&acc)[3], h8_t (&pf)[
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j, s = 32 * m + 8 * g + 4 * hh + j;
-                float a = acc[m][i] * scale_log2e;
-                if (brow) a = fmaf(bias[j] * mul1, mm, a);
-                a = s < S ? a : -INFINITY;
+                float a = acc[m][i];
+                if (brow) a = fmaf(bias[j], bmul, a);
+                if (decltype(masked)::value) a = s < S ? a : -INFINITY;
                 acc[m][i] = a;
                 mx = fmaxf(mx, a);
             }
         }
+    };
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if (32 * m + 32 <= S) pass1(m, std::false_type{});     // every key of the tile is real: no select
+        else pass1(m, std::true_type{});
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float nm = -mx * scale_log2e;
     float sum = 0.f;
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float e = __builtin_amdgcn_exp2f(acc[m][i] - mx);    // exp2(-inf) = 0 for masked keys
+            const float e = __builtin_amdgcn_exp2f(fmaf(acc[m][i], scale_log2e, nm));   // exp2(-inf) = 0 for masked keys
             acc[m][i] = e;
             sum += e;
         }
@@ -267,6 +304,11 @@ inline void plan_tiles(XattnParams& p, int tiles_per_wave_hint = 0) {
     p.tiles_per_wave = tpw;
     p.nchunks = (tiles + 4 * tpw - 1) / (4 * tpw);
     p.npart = (p.Bc / p.n_groups) * p.H * p.nchunks;
+    {
+        const double n = (double)(p.Bc / p.n_groups) * p.H * (double)p.L * p.S;
+        p.inv_n = 1.0 / n;
+        p.inv_nm1 = 1.0 / (n - 1.0);                          // (a single score: inf, 0 * inf = nan - what torch.std gives)
+    }
     p.xcd_map = ((p.Bc * p.nchunks) % 8 == 0) ? 1 : 0;
 }
 

@@ -441,8 +441,8 @@ def test_shared_cfg_prefix_equals_the_full_batch(sd15):
 
 # ------------------------------------------------------------------ end-to-end: all 25 steps, the north star's stated tolerance
 # Observed on MI355X (round 3; printed by the test): see DESIGN.md section 2 for the numbers these bounds were derived from.
-FINAL_LATENT_TOL_MAX = 1.5e-2          # max |final latent - oracle| / oracle range, after 25 DPM++ 2M Karras steps
-FINAL_LATENT_TOL_MEAN = 2.0e-3         # mean |...| / range
+FINAL_LATENT_TOL_MAX = 8e-3            # max |final latent - oracle| / oracle range, after 25 DPM++ 2M Karras steps (observed 2.4e-3)
+FINAL_LATENT_TOL_MEAN = 1e-3           # mean |...| / range (observed 2.4e-4)
 
 
 @pytest.mark.parametrize("profile", ["latency", "throughput"])

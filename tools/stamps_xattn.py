@@ -22,7 +22,7 @@ for (Bc, H, L, d) in [(2, 8, 4096, 40), (2, 8, 64, 160)]:
             st = buf.cpu().view(4, 32, 2)[0]          # wave 0
             if bias:
                 tt = st[:, 0].tolist()
-                print(f"      prologue detail: issue loads {tt[7]-tt[0]} | partials+sigma arrive {tt[8]-tt[7]} | std reduce {tt[9]-tt[8]} | bias table {tt[1]-tt[9]}")
+                print(f"      prologue detail: DMA + Q + row loads issued {tt[7]-tt[0]} | partial loads issued {tt[8]-tt[7]} | rows + partials stored to LDS (loads landed) {tt[9]-tt[8]}")
             t = st[:, 0].tolist(); r = st[:, 1].tolist()
             mhz = (t[6] - t[0]) / max(r[6] - r[0], 1) * 100.0
             print(f"L{L} d{d} tpwflag={tpwflag} ref16={ref16} bias={'y' if bias else 'n'}: clock ~{mhz:.0f} MHz; cycles:", " | ".join(f"{names[i+1]} {t[i+1]-t[i]}" for i in range(6)), f"| total {t[6]-t[0]} cyc = {(r[6]-r[0])*10} ns")
