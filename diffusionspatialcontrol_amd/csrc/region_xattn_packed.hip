@@ -75,6 +75,55 @@ __device__ __forceinline__ void dma_image(const half_t* src, char* lds, int piec
                                          (__attribute__((address_space(3))) void*)(lds + pc * 1024), 16, 0, 0);
 }
 
+// global -> registers -> LDS copy of FR 1-KiB fragments by the whole workgroup: thread t moves the 16-byte chunks t, t + 256, ...
+// Two halves so that every load of the prologue is in flight before anything waits.  (Round 2 moved the image by LDS-DMA: no
+// register staging, but an LDS-DMA instruction holds its wave's issue port for 100-200 cycles - 5-6 of them per wave were
+// ~1300 cycles of the prologue before the first byte was even waited for; a 16-byte register load issues in a few cycles and
+// the ds_write_b128 behind it in ~13.)
+template <int FR>
+struct ImgCopy {
+    static constexpr int NCH = (FR * 64 + kThreads - 1) / kThreads;
+    h8_t st[NCH];
+    __device__ __forceinline__ void load(const half_t* src) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int idx = threadIdx.x + c * kThreads;
+            if (NCH * kThreads == FR * 64 || idx < FR * 64) st[c] = *reinterpret_cast<const h8_t*>(src + (long long)idx * 8);
+        }
+    }
+    __device__ __forceinline__ void store(half_t* lds) const {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int idx = threadIdx.x + c * kThreads;
+            if (NCH * kThreads == FR * 64 || idx < FR * 64) *reinterpret_cast<h8_t*>(lds + idx * 8) = st[c];
+        }
+    }
+};
+
+// K fragments of one (b, h) straight from the packed image into registers (statistics pass: nothing else of the image is
+// needed, and four waves reading 9-30 KiB each from L2 is cheaper than staging + a workgroup barrier)
+template <int NK>
+__device__ __forceinline__ void load_k_frags(const half_t* img, h8_t (&kf)[3 * NK], int lane) {
+#pragma unroll
+    for (int f = 0; f < 3 * NK; ++f) kf[f] = *reinterpret_cast<const h8_t*>(img + ((long long)f * 64 + lane) * 8);
+}
+
+template <int NK, bool REF16>
+__device__ __forceinline__ void scores_reg(const h8_t (&kf)[3 * NK], const h8_t (&qf)[NK], f16x_t (&acc)[3], float scale) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) acc[m] = mfma_32x32x16(kf[m * NK + ks], qf[ks], acc[m]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (REF16) acc[m][i] = round_f16(pin_f32(round_f16(acc[m][i]) * scale));   // attention_modify.py:90
+            else acc[m][i] = acc[m][i] * scale;
+        }
+    }
+}
+
 template <int NK, bool REF16, bool RAW = false>
 __device__ __forceinline__ void scores_img(const XattnParams& p, const half_t* img, const h8_t (&qf)[NK], f16x_t (&acc)[3],
                                            int lane, float scale) {
@@ -104,17 +153,14 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using P = PCfg<NK>;
     const XattnParams& p = pp.x;
-    half_t* img = reinterpret_cast<half_t*>(smem);
-    double* red = reinterpret_cast<double*>(smem + P::KFR * 1024);
+    double* red = reinterpret_cast<double*>(smem);
     int b, h, chunk;
     block_to_work(p, b, h, chunk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-    dma_image(pp.img + (long long)(b * p.H + h) * P::IMG, smem, P::KFR, wave, lane);
-    h8_t qf[NK];
+    h8_t qf[NK], kf[3 * NK];
     int l0 = (chunk * kWaves * p.tiles_per_wave + wave) * 32;
     load_q_frags<NK>(p, qf, b, h, min(l0 + r, p.L - 1), hh);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    load_k_frags<NK>(pp.img + (long long)(b * p.H + h) * P::IMG, kf, lane);
     double d1 = 0.0, d2 = 0.0;
     for (int t = 0; t < p.tiles_per_wave; ++t) {
         l0 = (chunk * kWaves * p.tiles_per_wave + t * kWaves + wave) * 32;
@@ -122,7 +168,7 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
         if (t > 0) load_q_frags<NK>(p, qf, b, h, min(l0 + r, p.L - 1), hh);
         const bool row_ok = l0 + r < p.L;
         f16x_t acc[3];
-        scores_img<NK, REF16>(p, img, qf, acc, lane, p.scale);
+        scores_reg<NK, REF16>(kf, qf, acc, p.scale);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m = 0; m < 3; ++m)
@@ -183,7 +229,16 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
     XP_STAMP(0)
 
     // ---- prologue: image DMA, first tile's Q / row id, std partials - all in flight together
-    dma_image(pp.img + (long long)(b * p.H + h) * P::IMG, smem, P::KFR + P::VFR, wave, lane);
+    // The statistics partials first: they were written by the OTHER XCDs' workgroups of the launch before this one, i.e. they
+    // come from beyond this XCD's L2 - the longest latency of the prologue, so it starts first and everything else hides under it
+    PartialLoads pl;
+    float sd = 1.f, sig = 1.f;
+    if (has_bias) {
+        pl.issue(p, b % p.n_groups);
+        sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
+    }
+    ImgCopy<P::KFR + P::VFR> imgc;
+    imgc.load(pp.img + (long long)(b * p.H + h) * P::IMG);
     h8_t qf[NK];
     int l0 = (chunk * kWaves * p.tiles_per_wave + wave) * 32;
     bool tile_ok = l0 < p.L;
@@ -193,38 +248,56 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
         load_q_frags<NK>(p, qf, b, h, row, hh);
         if (has_bias) id = pp.ids[(long long)bw * p.L + row];
     }
-    float sd = 1.f, sig = 1.f;
-    // distinct rows -> LDS: thread t owns key column t % 128 of rows t / 128, t / 128 + 2, ... - ONE lane mask (s < S) for all
-    // sixteen loads and a wave-uniform row test, instead of thirteen (row, column) masks that the compiler kept in (spilled)
-    // SGPRs between the loads and the stores.  Columns [S, kBP) of the table stay unwritten: a score that reads them is beyond
-    // the last key and is replaced by -inf with a select, never used in arithmetic.
+    // distinct rows -> LDS.  DSC_FLAG_ROWS_PADDED (what the pipeline passes): the caller's table already has the LDS table's
+    // shape - [NU][kBP] fp32, 16-byte aligned - so it is a flat copy of 16-byte chunks, at most four per thread.  Otherwise
+    // ([NU][S], S odd in general): thread t owns key column t % 128 of rows t / 128, t / 128 + 2, ... - ONE lane mask (s < S)
+    // for all sixteen loads and a wave-uniform row test.  Columns [S, kBP) may stay unwritten: a score that reads them is
+    // beyond the last key and is replaced by -inf with a select, never used in arithmetic.
     constexpr int kRowRegs = kNUMax / 2;
+    constexpr int kRowVec = (kNUMax * kBP / 4 + kThreads - 1) / kThreads;      // 4
     if (has_bias) {
+        const bool padded = (p.flags & DSC_FLAG_ROWS_PADDED) != 0;
         float rowv[kRowRegs];
+        f4x_t rvec[kRowVec];
         const int bs = threadIdx.x & 127, bu = threadIdx.x >> 7;
+        if (padded) {
 #pragma unroll
-        for (int c = 0; c < kRowRegs; ++c) {
-            const int u = bu + 2 * c;
-            rowv[c] = 0.f;
-            if (u < pp.NU && bs < p.S) rowv[c] = pp.rows[u * p.S + bs];
+            for (int c = 0; c < kRowVec; ++c) {
+                const int idx = threadIdx.x + c * kThreads;
+                if (idx * 4 < pp.NU * kBP) rvec[c] = reinterpret_cast<const f4x_t*>(pp.rows)[idx];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < kRowRegs; ++c) {
+                const int u = bu + 2 * c;
+                rowv[c] = 0.f;
+                if (u < pp.NU && bs < p.S) rowv[c] = pp.rows[u * p.S + bs];
+            }
         }
         XP_STAMP(7)
-        double a1, a2;
-        group_partials(p, b % p.n_groups, a1, a2);
-        sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
         XP_STAMP(8)
+        if (padded) {
 #pragma unroll
-        for (int c = 0; c < kRowRegs; ++c) {
-            const int u = bu + 2 * c;
-            if (u < pp.NU && bs < p.S) biasT[u * kBP + bs] = rowv[c];
+            for (int c = 0; c < kRowVec; ++c) {
+                const int idx = threadIdx.x + c * kThreads;
+                if (idx * 4 < pp.NU * kBP) reinterpret_cast<f4x_t*>(biasT)[idx] = rvec[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < kRowRegs; ++c) {
+                const int u = bu + 2 * c;
+                if (u < pp.NU && bs < p.S) biasT[u * kBP + bs] = rowv[c];
+            }
         }
+        double a1, a2;
+        pl.finish(p, a1, a2);
         group_std_stage(a1, a2, red);
         XP_STAMP(9)
     }
     XP_STAMP(1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the DMA'd image has landed (this wave's pieces)
+    imgc.store(img);                                         // (waits for this thread's chunks)
     XP_STAMP(2)
-    __syncthreads();                                         // ... and everyone else's; raw rows and partial pairs are in LDS
+    __syncthreads();                                         // the image, the raw rows and the partial pairs are in LDS
     XP_STAMP(3)
     if (has_bias) sd = group_std_reduce(p, red, REF16);      // per wave, no barrier: overlaps the first tile's score MFMAs
 
@@ -533,7 +606,7 @@ int launch_packed(const XpParams& pp, bool need_stats, hipStream_t st) {
         attr_set = true;
     }
     if (need_stats)
-        DSC_LAUNCH((xp_stats<NK, REF16>), grid, block, (size_t)P::KFR * 1024 + kRedBytes, st, pp);
+        DSC_LAUNCH((xp_stats<NK, REF16>), grid, block, (size_t)kRedBytes, st, pp);
     const size_t lds = (size_t)P::IMG * 2 + (size_t)kNUMax * kBP * 4 + kRedBytes;
     if constexpr (!REF16 && (NK == 3 || NK == 10)) {           // the diagnostic instantiation (tools/stamps_xattn.py's two shapes)
         if (pp.x.flags & 32u) {
@@ -614,6 +687,7 @@ extern "C" int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv,
     if (has_bias) {
         if (!region_rows || n_rows <= 0 || Bw <= 0 || (Bc * H) % Bw != 0) return DSC_ERR_BAD_ARG;
         if (n_rows > kNUMax) return DSC_ERR_UNSUPPORTED;
+        if ((flags & DSC_FLAG_ROWS_PADDED) && (nkc > 1 || !aligned16(region_rows))) return DSC_ERR_UNSUPPORTED;
     }
     XpParams pp{};
     XattnParams& p = pp.x;

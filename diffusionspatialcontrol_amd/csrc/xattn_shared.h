@@ -139,6 +139,40 @@ __device__ __forceinline__ void group_partials(const XattnParams& p, int g, doub
         for (int u = 0; u < kPL; ++u) { a1 += v1[u]; a2 += v2[u]; }     // (+ 0.0 for the pairs past the end: exact)
     }
 }
+// the same sum in two halves: issue() starts this thread's first four loads and returns without using them, finish() - called
+// once every other load of the caller's prologue is in flight - adds them in group_partials' order (and walks any further
+// partials, npart > 4 * kThreads, with the plain loop).  Same bits as group_partials.
+struct PartialLoads {
+    static constexpr int kPL = 4;
+    double v1[kPL], v2[kPL];
+    const double* src;
+    __device__ __forceinline__ void issue(const XattnParams& p, int g) {
+        src = p.partials + (long long)g * p.npart * 2;
+#pragma unroll
+        for (int u = 0; u < kPL; ++u) {
+            const int i = threadIdx.x + u * kThreads;
+            v1[u] = 0.0; v2[u] = 0.0;
+            if (i < p.npart) { v1[u] = src[2 * i]; v2[u] = src[2 * i + 1]; }
+        }
+    }
+    __device__ __forceinline__ void finish(const XattnParams& p, double& a1, double& a2) const {
+        a1 = 0.0; a2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < kPL; ++u) { a1 += v1[u]; a2 += v2[u]; }
+        for (int i0 = threadIdx.x + kPL * kThreads; i0 < p.npart; i0 += kPL * kThreads) {
+            double w1[kPL], w2[kPL];
+#pragma unroll
+            for (int u = 0; u < kPL; ++u) {
+                const int i = i0 + u * kThreads;
+                w1[u] = 0.0; w2[u] = 0.0;
+                if (i < p.npart) { w1[u] = src[2 * i]; w2[u] = src[2 * i + 1]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kPL; ++u) { a1 += w1[u]; a2 += w2[u]; }
+        }
+    }
+};
+
 // `red` needs 2 * kThreads doubles of LDS, 16-byte aligned.  Two halves around ONE workgroup barrier (which a kernel can share
 // with the barrier that publishes its LDS images): every thread stores its pair; after the barrier each WAVE adds all 256 pairs
 // itself - lane i the pairs i, i + 64, i + 128, i + 192 in that order, then a fixed xor butterfly - so every lane of every wave
@@ -148,13 +182,33 @@ __device__ __forceinline__ void group_std_stage(double a1, double a2, double* re
     red[2 * threadIdx.x] = a1;
     red[2 * threadIdx.x + 1] = a2;
 }
+// all-lanes sum of a double over the wave with the first four exchange steps on DPP (a few cycles each: lane ^ 1, lane ^ 2, the
+// other quad of the 8-lane group by row_half_mirror, the other half of the 16-lane row by row_mirror) and only the last two
+// (lanes 16 and 32 apart) through the LDS crossbar (__shfl_xor: ~100 cycles of dependent latency each - six of those, twice,
+// in front of every workgroup's softmax were ~1100 cycles).  Every step adds two values that are uniform over the group they
+// come from, and a + b = b + a bit for bit: all 64 lanes end with the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_allsum_f64(double x) {
+    x += dpp_move_f64<0xB1>(x);          // quad_perm [1, 0, 3, 2]
+    x += dpp_move_f64<0x4E>(x);          // quad_perm [2, 3, 0, 1]
+    x += dpp_move_f64<0x141>(x);         // row_half_mirror
+    x += dpp_move_f64<0x140>(x);         // row_mirror
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
 __device__ __forceinline__ float group_std_reduce(const XattnParams& p, const double* red, bool ref16) {
     const int lane = threadIdx.x & 63;
     double t1 = 0.0, t2 = 0.0;
 #pragma unroll
     for (int w = 0; w < kThreads / 64; ++w) { t1 += red[2 * (lane + 64 * w)]; t2 += red[2 * (lane + 64 * w) + 1]; }
-    t1 = wave_sum_f64(t1);                                   // xor butterfly: commutative pair sums, the same bits in every lane
-    t2 = wave_sum_f64(t2);
+    t1 = wave_allsum_f64(t1);
+    t2 = wave_allsum_f64(t2);
     // unbiased variance (torch.std default) with the two reciprocals from the host (fp64 divides are ~30-instruction
     // sequences and this runs in every wave of every workgroup), the cancellation-prone subtraction still in fp64; the square
     // root in fp32 (the oracle's std is an fp32 tensor: one more rounding at 6e-8)

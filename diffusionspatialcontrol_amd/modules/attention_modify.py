@@ -94,6 +94,8 @@ def compressed_table(w, device):
     if hit is not None and hit[0] is w:
         return hit[1]
     comp = ops.compress_region_table(resident_table(w, device))
+    if comp is not None and comp[1].shape[1] <= 96:
+        comp = (comp[0], ops.pad_region_rows(comp[1]))
     _COMPRESSED_CACHE[key] = (w, comp)
     while len(_COMPRESSED_CACHE) > 64:
         _COMPRESSED_CACHE.popitem(last=False)

@@ -11,6 +11,8 @@ from . import _lib
 FLAG_REF_FP16_ROUNDING = 1
 FLAG_BIAS_IS_FINAL = 2
 FLAG_REUSE_STATS = 4
+FLAG_ROWS_PADDED = 256
+REGION_ROW_STRIDE = 100    # region_xattn_packed.hip kBP: the forward kernel's LDS bias-table row stride (floats)
 
 def _stream_ptr(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
@@ -177,10 +179,21 @@ def compress_region_table(w, pad_rows=False):
     return inv.reshape(Bw, L).to(torch.int16).contiguous(), rows.contiguous()
 
 
+def pad_region_rows(rows):
+    """distinct region rows [NU, S] (compress_region_table) -> [NU, 100] fp32, zero padded: the shape of the forward kernel's LDS
+    table, which it then fills with a flat 16-byte copy (DSC_FLAG_ROWS_PADDED).  S <= 96."""
+    NU, S = rows.shape
+    if S > 96:
+        raise ValueError("pad_region_rows: at most 96 keys (one text chunk)")
+    out = rows.new_zeros((NU, REGION_ROW_STRIDE), dtype=torch.float32)
+    out[:, :S] = rows
+    return out
+
+
 def region_xattn_packed(q, packed_kv, S, region=None, sigma=1.0, *, n_std_groups=1, scale=None, ref_fp16_rounding=True,
                         out=None, reuse_stats=False, debug_flags=0):
     """dsc_region_xattn_fwd_packed: q [Bc,L,H,d] view, packed_kv from xattn_kv_pack, region = (ids, rows) from
-    compress_region_table (device tensors) or None -> out [Bc,L,H,d] contiguous."""
+    compress_region_table (device tensors; rows optionally through pad_region_rows) or None -> out [Bc,L,H,d] contiguous."""
     _require_gpu(q, packed_kv)
     lib = _lib.load_library()
     qs, (Bc, H, L, d) = _blhd_strides(q, "blc")
@@ -198,6 +211,8 @@ def region_xattn_packed(q, packed_kv, S, region=None, sigma=1.0, *, n_std_groups
     else:
         sig_host = float(sigma)
     flags = (FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0) | (FLAG_REUSE_STATS if reuse_stats else 0) | debug_flags
+    if rows is not None and rows.shape[1] == REGION_ROW_STRIDE and S <= 96:      # pad_region_rows() form ([NU, S] has S <= 96 columns)
+        flags |= FLAG_ROWS_PADDED
     ws = _workspace(q.device, lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups))
     rc = lib.dsc_region_xattn_fwd_packed(_p(q), _p(packed_kv), _p(out), _p(ids), _p(rows), nrows, Bc, H, L, S, d, Bw,
                                          n_std_groups, _i64x3(*qs), _i64x3(*os_), sig_host, sig_dev,

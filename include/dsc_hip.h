@@ -38,6 +38,9 @@ extern "C" {
                                           and the softmax output (:101) */
 #define DSC_FLAG_REUSE_STATS       4u  /* measurement aid: skip the statistics launch and reuse the partial sums the
                                           previous identical call left in `workspace` (times the forward kernel alone) */
+#define DSC_FLAG_ROWS_PADDED     256u  /* dsc_region_xattn_fwd_packed only: `region_rows` is [n_rows][100] fp32 (row stride 100
+                                          floats = the kernel's LDS table, zeros beyond column S, 16-byte aligned) instead
+                                          of [n_rows][S]: the table goes to LDS as a flat 16-byte copy.  S <= 96 only. */
 #define DSC_FLAG_BIAS_IS_FINAL     2u  /* `region` already holds the additive bias (a custom weight_func was
                                           evaluated by the caller): add it as is, skip the statistics pass */
 

@@ -194,6 +194,11 @@ def test_packed_path_equals_generic_and_oracle(ops, Bc, H, L, S, d, Bw, ng):
     q_blhd = qd.transpose(1, 2)                                              # [Bc, L, H, d] strided view
     out = ops.region_xattn_packed(q_blhd, packed, S, (ids, rows), 2.0, n_std_groups=ng)
     assert torch.equal(out.transpose(1, 2), gen)
+    # the rows in the kernel's own table shape ([NU, 100], what the pipeline uploads: a flat 16-byte copy into LDS): same bits
+    for r16 in (True, False):
+        a_ = ops.region_xattn_packed(q_blhd, packed, S, (ids, rows), 2.0, n_std_groups=ng, ref_fp16_rounding=r16)
+        b_ = ops.region_xattn_packed(q_blhd, packed, S, (ids, ops.pad_region_rows(rows)), 2.0, n_std_groups=ng, ref_fp16_rounding=r16)
+        assert torch.equal(a_, b_)
     exp = ra.region_attention(q, k, v, w, 2.0, n_std_groups=ng, fp16_rounding=True)
     err = (out.transpose(1, 2).float().cpu() - exp).abs()
     assert err.max().item() < tol16(q, k, w, 2.0, ng)

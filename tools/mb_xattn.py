@@ -35,7 +35,7 @@ if which == "xattn":
         alg = Bc * (2 * (2 * L * C + 2 * S * C) + 4 * L * S)
         t_exit = tm_graph(lambda: f(region=None, debug_flags=8)); t_pro = tm_graph(lambda: f(region=None, debug_flags=16))
         print(f"   probes: exit-at-start {t_exit:.2f} us, prologue-only {t_pro:.2f} us")
-        packed = ops.xattn_kv_pack(k4, v4); comp = ops.compress_region_table(w)
+        packed = ops.xattn_kv_pack(k4, v4); comp = ops.compress_region_table(w, pad_rows=True); comp = (comp[0], ops.pad_region_rows(comp[1]))
         fp = lambda **kw: ops.region_xattn_packed(q4, packed, S, kw.pop("region", comp), sig, n_std_groups=ng, out=out, **kw)
         fp()
         tp_pair = tm_graph(lambda: fp()); tp_fwd = tm_graph(lambda: fp(reuse_stats=True)); tp_nob = tm_graph(lambda: fp(region=None))
