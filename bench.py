@@ -569,8 +569,9 @@ def main():
             _lib.load_library().dsc_linear_lt_stats(st3)
             res["config"]["library_gemm_algorithms"] = {"shapes": int(st3[0]), "candidates_offered": int(st3[1]),
                                                         "dropped_needing_workspace": int(st3[2]),
-                                                        "note": "only workspace-free hipBLASLt algorithms are eligible (no stream-K / split-K "
-                                                                "kernels whose workgroups wait on each other): linear_lt.hip"}
+                                                        "note": "shapes = 0: no GEMM of the run went to hipBLASLt (every linear on gemm_tn_f16 / "
+                                                                "split-K, ops.USE_LIBRARY_GEMM off); DSC_LIBRARY_GEMM=1 restores the library "
+                                                                "routing, workspace-free algorithms only (linear_lt.hip)"}
         except Exception:  # noqa: BLE001
             pass
         print(json.dumps(res), flush=True)

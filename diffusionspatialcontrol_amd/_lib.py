@@ -88,6 +88,9 @@ _SIGNATURES = {
                                           ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, _vp, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_add_layernorm": (ctypes.c_int, [_vp] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_int, _vp]),
     "dsc_geglu": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
+    "dsc_linear_splitk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dsc_linear_splitk_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
+                              [ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
     "dsc_softmax_rows_f16": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_float,
                                             ctypes.c_int, _vp]),
 }

@@ -54,7 +54,14 @@ struct GemmParams {
     // stride ldo), columns [C, 3C) to kv[which][b][h][l][dd] - each head's keys / values contiguous, so that the flash
     // kernel's 64-key tiles are plain contiguous 1-KiB DMA pieces instead of 80-byte row segments 1920 bytes apart
     half_t* kv; int kv_C, kv_H, kv_d, kv_L, kv_B;
-    int xcd_remap, total;        // virtual workgroup order (see the kernel) and the number of real tiles
+    int xcd_remap, total;        // virtual workgroup order (see the kernel) and the number of real workgroups (tiles x splits)
+    // split-K (dsc_linear_splitk_f16): workgroup (tile, split sp) multiplies K tiles [sp * kps, sp * kps + kps) and writes its raw
+    // fp32 tile to ws[sp][m][n]; gemm_splitk_reduce adds the splits in order (+ bias + residual): bit-reproducible.  For the
+    // few-row, long-K GEMMs of the 16x16 / 8x8 levels (M <= 512, K = 1920 ... 5120), which are bound by how many bytes of
+    // WEIGHTS are in flight: 40-160 workgroups walking 30-80 K tiles each with two or three tiles in flight cannot pull 13 MB
+    // of cold weights out of HBM quickly, four to eight times as many workgroups can.
+    int splits, kps, tiles;
+    float* ws;
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -130,6 +137,12 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         bid = (bid & 7) * per + (bid >> 3);
         if (bid >= p.total) return;                          // grid padded to a multiple of 8 (before any barrier)
     }
+    int kbeg = 0;                                            // first K tile of this workgroup (split-K)
+    if (p.splits > 1) {
+        const int sp = bid / p.tiles;
+        bid -= sp * p.tiles;
+        kbeg = sp * p.kps;
+    }
     const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel
     const int m0 = bm * BM;
     const int n0 = GEGLU ? bn * (32 * NT) : bn * BNT;
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     const int iw = LOADER ? wave - 4 : wave;                 // index among the issuing waves
     auto issue = [&](int kt, int buf) {
         half_t* a = lds + buf * kStage;
-        dma_tile<BM, NISS>(p.x, p.ldx, m0, p.M, kt * BK, a, iw, lane);
+        dma_tile<BM, NISS>(p.x, p.ldx, m0, p.M, (kbeg + kt) * BK, a, iw, lane);
         if (GEGLU) {
             // B tile rows 0..32NT-1 = w[n0 ..), rows 32NT.. = w[Nh + n0 ..): two half-tiles
             half_t* b = a + kAHalves;
@@ -148,12 +161,12 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                 const int row = piece * 8 + (lane >> 3);
                 const int grow = (row < 32 * NT ? n0 + row : Nh + n0 + row - 32 * NT);
                 const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-                const half_t* src = p.w + (long long)grow * p.K + kt * BK + chunk * 8;
+                const half_t* src = p.w + (long long)grow * p.K + (kbeg + kt) * BK + chunk * 8;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(b + piece * 512), 16, 0, 0);
             }
         } else {
-            dma_tile<BNT, NISS>(p.w, p.K, n0, p.N, kt * BK, a + kAHalves, iw, lane);
+            dma_tile<BNT, NISS>(p.w, p.K, n0, p.N, (kbeg + kt) * BK, a + kAHalves, iw, lane);
         }
     };
 
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk = p.splits > 1 ? min(p.K / BK - kbeg, p.kps) : p.K / BK;
     // tile kt has landed once at most min(STAGES-2, nk-1-kt) younger tiles (kPieces DMA instructions each) are outstanding
     auto wait_tile = [&](int kt) {
         const int younger = min(STAGES - 2, nk - 1 - kt);
@@ -310,6 +323,20 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             kv_b0 = m0 / p.kv_L;                                  // scalar: the block's first token row
             kv_l0 = m0 - kv_b0 * p.kv_L;
         }
+        if (p.ws) {                                               // split-K: the raw fp32 tile of this split, nothing else
+            float* wsp = p.ws + (long long)(kbeg / p.kps) * p.M * p.N;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
+                if (m0 + row < p.M) {
+                    const float* sp = stage + row * kES + ch * 8;
+                    float* dst = wsp + (long long)(m0 + row) * p.N + n0 + ch * 8;
+                    *reinterpret_cast<f4x_t*>(dst) = *reinterpret_cast<const f4x_t*>(sp);
+                    *reinterpret_cast<f4x_t*>(dst + 4) = *reinterpret_cast<const f4x_t*>(sp + 4);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
@@ -351,6 +378,30 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     }
 }
 
+// out = sum over the splits (in split order) + bias + residual, one fp16 rounding (the second launch of dsc_linear_splitk_f16)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* ws, const half_t* bias, const half_t* res, half_t* out,
+                                                          long long M, int N, int splits, long long ldr, long long ldo) {
+    const int cv = N / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * cv) return;
+    const long long m = idx / cv;
+    const int n = (int)(idx - m * cv) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < splits; ++k) {
+        const float* src = ws + ((long long)k * M + m) * N + n;
+        const f4x_t a = *reinterpret_cast<const f4x_t*>(src), b = *reinterpret_cast<const f4x_t*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+    }
+    h8_t bv = {0, 0, 0, 0, 0, 0, 0, 0}, rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (bias) bv = *reinterpret_cast<const h8_t*>(bias + n);
+    if (res) rv = *reinterpret_cast<const h8_t*>(res + m * ldr + n);
+    h8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)(acc[j] + (float)bv[j] + (float)rv[j]);
+    *reinterpret_cast<h8_t*>(out + m * ldo + n) = o;
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
@@ -388,7 +439,7 @@ namespace {
 int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
-                int dtype, void* stream, void* kv_out, int heads, int seq_len);
+                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits = 1, float* ws = nullptr);
 }
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -413,7 +464,7 @@ namespace {
 int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
-                int dtype, void* stream, void* kv_out, int heads, int seq_len) {
+                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits, float* ws) {
     if ((ln_in && (!ln_cvec || ln_nb <= 0)) || (ln_out && geglu)) return DSC_ERR_BAD_ARG;
     if (ln_in && !al16(ln_cvec)) return DSC_ERR_UNSUPPORTED;       // read as float4 pairs
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
@@ -458,8 +509,17 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // the kernel is L2->LDS bandwidth bound at this tile size (43 FLOP per staged byte), which caps it near 25 % of the
     // MFMA peak; the dispatch in ops.linear therefore sends long-K shapes to hipBLASLt's larger macro-tiles.
     p.xcd_remap = g_gemm_xcd == 0 ? (M >= 2ll * N ? 1 : 0) : (g_gemm_xcd == 2 ? 1 : 0);
-    p.total = mb * nb;
-    const dim3 grid(p.xcd_remap ? ((mb * nb + 7) / 8) * 8 : mb * nb), block(T);
+    p.tiles = mb * nb;
+    p.splits = 1;
+    if (splits > 1) {                                            // split-K: raw fp32 tiles to ws, no epilogue operands
+        const int nkt = K / BK;
+        p.kps = (nkt + splits - 1) / splits;
+        p.splits = (nkt + p.kps - 1) / p.kps;
+        p.ws = ws;
+        p.bias = nullptr; p.res = nullptr;
+    }
+    p.total = p.tiles * p.splits;
+    const dim3 grid(p.xcd_remap ? ((p.total + 7) / 8) * 8 : p.total), block(T);
     // Two stages (48 KiB: three workgroups per CU instead of two) for grids of many workgroups per CU: with K = 320 / 640 the
     // K loop is a third of a workgroup's time (prologue DMA chain, LayerNorm / GEGLU epilogue), and a third co-resident
     // workgroup overlaps those parts (tools/mb_gemm.py)
@@ -472,11 +532,11 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // back-to-back micro-benchmark (warm weights) ranks the other way round.  So: two stages only for the 128-row many-workgroup grids.
     // (5- and 8-stage rings for the 64-row tiles of the small grids, in the step: M=512 N=1280 K=1280 10.8 -> 11.0 / 11.2 us,
     // M=2048 N=640 K=640 9.0 -> 9.9: the K loop is bound by what one CU ingests from L2, not by DMA latency, cold weights or not)
-    const int stages = g_gemm_stages ? g_gemm_stages : ((K <= 1280 && bm == 128 && mb * nb >= 300) ? 2 : 3);
+    const int stages = g_gemm_stages ? g_gemm_stages : ((K <= 1280 && bm == 128 && mb * nb >= 300 && p.splits == 1) ? 2 : 3);
     // 128-column tiles (two stages of 32 KiB, two workgroups per CU) where the grid still gives every CU a workgroup: the
     // GEGLU GEMMs (N/2 = 1280 / 2560 / 5120 -> 1280 / 640 / 320 workgroups)
     const bool wide_ok = bm == 128 && N % 128 == 0 && (!geglu || (N / 2) % 64 == 0) && (g_gemm_stages == 0 || g_gemm_stages == 2) && g_gemm_loaders != 4;
-    const bool wide = wide_ok && (g_gemm_nt == 2 || (g_gemm_nt == 0 && geglu && (long long)mb * (N / 128) >= 256));
+    const bool wide = wide_ok && p.splits == 1 && (g_gemm_nt == 2 || (g_gemm_nt == 0 && geglu && (long long)mb * (N / 128) >= 256));
     if (wide) {
         nb = N / 128;
         p.total = mb * nb;
@@ -517,3 +577,42 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
 }
 }  // namespace
 
+// K tiles per split: as many splits as bring the grid to ~512 workgroups, at least 8 K tiles each
+static int splitk_auto(int64_t M, int N, int K) {
+    const int nkt = K / BK;
+    const long long tiles = ((M + 63) / 64) * (N / BN);
+    long long want = tiles > 0 ? 512 / tiles : 1;
+    if (want > nkt / 8) want = nkt / 8;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+extern "C" size_t dsc_linear_splitk_workspace_bytes(int64_t M, int N, int K, int splits) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % BN != 0) return 0;
+    if (splits <= 0) splits = splitk_auto(M, N, K);
+    const int nkt = K / BK, kps = (nkt + splits - 1) / splits;
+    splits = (nkt + kps - 1) / kps;
+    return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
+extern "C" int dsc_linear_splitk_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                     int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int splits,
+                                     void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16 || K % BK != 0 || N % BN != 0) return DSC_ERR_UNSUPPORTED;
+    if (splits <= 0) splits = splitk_auto(M, N, K);
+    const int nkt = K / BK, kps = (nkt + splits - 1) / splits;
+    splits = (nkt + kps - 1) / kps;
+    if (splits <= 1) return dsc_linear_f16(x, w, bias, residual, out, M, N, K, ldx, ldr, ldo, 0, dtype, stream);
+    const size_t need = (size_t)splits * M * N * sizeof(float);
+    if (!workspace || workspace_bytes < need || !al16(workspace)) return DSC_ERR_WORKSPACE;
+    if ((bias && !al16(bias)) || (residual && (!al16(residual) || ldr % 8 != 0)) || ldo % 8 != 0 || !al16(out)) return DSC_ERR_UNSUPPORTED;
+    const int rc = linear_impl(x, w, nullptr, nullptr, out, M, N, K, ldx, 0, ldo, 0, nullptr, 0, nullptr, 0.f, nullptr, dtype, stream,
+                               nullptr, 0, 0, splits, static_cast<float*>(workspace));
+    if (rc != DSC_OK) return rc;
+    const long long n8 = M * (N / 8);
+    DSC_LAUNCH(gemm_splitk_reduce, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+               static_cast<const float*>(workspace), static_cast<const half_t*>(bias), static_cast<const half_t*>(residual),
+               static_cast<half_t*>(out), (long long)M, N, splits, (long long)ldr, (long long)ldo);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}

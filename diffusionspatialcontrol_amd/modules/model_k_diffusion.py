@@ -1194,7 +1194,12 @@ class StableDiffusionPipeline:
         from .u_net_condition_modify import Attention
         for m in self.unet.modules():
             if isinstance(m, Attention) and m.is_cross_attention:
-                k, v = m.to_k(text), m.to_v(text)
+                if text.is_cuda and text.dtype == torch.float16 and type(m.to_k) is torch.nn.Linear and m.to_k.bias is None:
+                    # the package's own GEMM (as every linear of the step): the same bits in every process / on every rank
+                    k = ops.linear(text, m.to_k.weight, prefer_kernel=True)
+                    v = ops.linear(text, m.to_v.weight, prefer_kernel=True)
+                else:
+                    k, v = m.to_k(text), m.to_v(text)
                 B, S, C = k.shape
                 d = C // m.heads
                 # one entry per static text buffer (= per generation slot); the newest few are kept

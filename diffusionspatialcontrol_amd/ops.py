@@ -360,8 +360,14 @@ def groupnorm_silu_nhwc_cat(x1, x2, groups, weight, bias, eps, act, add=None):
     return y, cat
 
 
-USE_LT_RESIDUAL = os.environ.get("DSC_LT_RESIDUAL", "1") != "0"   # GEMMs left to hipBLASLt take bias + residual in the same launch (dsc_linear_lt_f16)
-USE_LT_ALL = os.environ.get("DSC_LT_ALL", "1") != "0"   # ... and the ones without a residual go the same way (measured algorithm choice, DSC_LT_TUNE)
+# Library GEMMs (hipBLASLt through dsc_linear_lt_f16) are OFF by default since round 3: every linear of the step runs on the
+# package's own kernels (gemm_tn_f16, split-K for the few-row long-K shapes).  Per step that costs ~20 us against the best of
+# both per shape (tools/mb_gemm_cold.py) and buys: the same bits in every process, on every rank and under both tuning profiles
+# (the library's algorithm was timed per process and differed per profile), no 0.3 s of algorithm timing at start-up, and no
+# stream-K kernels in a step that runs on two streams.  DSC_LIBRARY_GEMM=1 restores the round-2 routing for A/B measurements.
+USE_LIBRARY_GEMM = os.environ.get("DSC_LIBRARY_GEMM", "0") != "0"
+USE_LT_RESIDUAL = USE_LIBRARY_GEMM and os.environ.get("DSC_LT_RESIDUAL", "1") != "0"   # bias + residual in the library launch (dsc_linear_lt_f16)
+USE_LT_ALL = USE_LIBRARY_GEMM and os.environ.get("DSC_LT_ALL", "1") != "0"   # ... and the ones without a residual go the same way
 USE_DSC_GEMM = True        # route qualifying linears to dsc_linear_f16 (False: always hipBLASLt through torch)
 DSC_GEMM_MIN_ROWS = 1024   # measured (tools/mb_gemm.py): the 128x64x64-tile kernel beats hipBLASLt + separate epilogue
 DSC_GEMM_MAX_K = int(os.environ.get("DSC_GEMM_MAX_K", "640"))       # kernels for >= 1024 token rows and K <= 640; hipBLASLt's larger macro-tiles win beyond
@@ -476,6 +482,26 @@ def linear_qkv(x, weight, bias, heads, ln=None):
     return q.view(B, L, heads, d), kv[0].permute(0, 2, 1, 3), kv[1].permute(0, 2, 1, 3)
 
 
+USE_SPLITK = os.environ.get("DSC_GEMM_SPLITK", "1") != "0"    # few-row long-K GEMMs on dsc_linear_splitk_f16 instead of the library
+SPLITK_MAX_ROWS = int(os.environ.get("DSC_SPLITK_MAX_ROWS", "512"))
+SPLITK_MIN_K = int(os.environ.get("DSC_SPLITK_MIN_K", "1920"))
+
+
+def linear_splitk(x2, weight, bias, r2, splits=0):
+    """dsc_linear_splitk_f16 on 2-D operands (x2 [M, K], weight [N, K] contiguous, r2 [M, N] or None) -> [M, N]"""
+    lib = _lib.load_library()
+    M, K = x2.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=x2.dtype, device=x2.device)
+    nbytes = lib.dsc_linear_splitk_workspace_bytes(M, N, K, splits)
+    ws = _workspace(x2.device, nbytes) if nbytes else None
+    rc = lib.dsc_linear_splitk_f16(_p(x2), _p(weight), _p(bias), _p(r2), _p(out), M, N, K, x2.stride(0),
+                                   r2.stride(0) if r2 is not None else 0, N, splits, _p(ws), ws.numel() * 8 if ws is not None else 0,
+                                   0, _stream_ptr(x2))
+    _lib.check(rc, "dsc_linear_splitk_f16")
+    return out
+
+
 def linear(x, weight, bias=None, residual=None, geglu=False, prefer_kernel=False):
     """x @ weight.T (+ bias) (+ residual), or the fused GEGLU of [x @ weight.T + bias]; x [..., K], weight [N, K].
     prefer_kernel: take the hand-written GEMM whenever it CAN run the shape, whatever the row / K thresholds say.
@@ -501,6 +527,12 @@ def linear(x, weight, bias=None, residual=None, geglu=False, prefer_kernel=False
         r2 = residual.reshape(M, N)
         can = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
     ok = can and (prefer_kernel or _gemm_rows_k_preferred(M, K, geglu))
+    if can and not ok and not geglu and USE_SPLITK and not USE_LIBRARY_GEMM and M <= SPLITK_MAX_ROWS and K >= SPLITK_MIN_K \
+            and (bias is None or (bias.dtype == torch.float16 and bias.data_ptr() % 16 == 0)):
+        # few rows, long K (the 16x16 / 8x8 levels' feed-forward output projections and shortcut 1x1s): weight-streaming bound,
+        # split-K over workgroups + an ordered reduce launch (bias / residual there) - measured against the library per shape
+        # in the step's cache state (tools/mb_gemm_cold.py)
+        return linear_splitk(x2, weight, bias, residual.reshape(M, N) if residual is not None else None).reshape(*lead, N)
     if not ok:
         if ((USE_LT_RESIDUAL if residual is not None else USE_LT_ALL) and x.dtype == torch.float16 and K % 8 == 0
                 and N % 8 == 0 and M >= 8 and not (geglu and residual is not None)):

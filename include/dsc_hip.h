@@ -394,6 +394,21 @@ int dsc_add_layernorm(const void* x, const void* a, const void* gamma, const voi
 int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);
 
 /*
+ * Split-K form of dsc_linear_f16 for few-row, long-K projections - out = x . w^T (+ bias) (+ residual) - the feed-forward
+ * output projections (`ff.net.2`, K = 4C) and the 1x1 `conv_shortcut`s on concatenated skips (K = 1920 / 2560) of the 16x16 and
+ * 8x8 UNet levels that modules/u_net_condition_modify.py builds from diffusers blocks (M = 128 / 512 token rows at batch 1).
+ * Those GEMMs are bound by how many bytes of cold WEIGHTS are in flight, so the K tiles are dealt over `splits` workgroups per
+ * output tile (splits <= 0: chosen from the shape), each writes its raw fp32 tile to `workspace` ([splits][M][N] fp32,
+ * dsc_linear_splitk_workspace_bytes; 16-byte aligned) and a second launch adds the splits IN ORDER, then bias and residual, with
+ * one fp16 rounding: bit-reproducible, no atomics, no workgroup waits on another.  Same operand constraints as dsc_linear_f16
+ * (K % 64 == 0, N % 64 == 0, 16-byte aligned rows); splits == 1 after clamping runs dsc_linear_f16 itself.
+ */
+size_t dsc_linear_splitk_workspace_bytes(int64_t M, int N, int K, int splits);
+int dsc_linear_splitk_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                          int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int splits,
+                          void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
+/*
  * Row softmax of materialised fp16 scores: probs[r, :] = softmax(scale * scores[r, :]), fp32 arithmetic, one fp16 rounding.
  * The middle step of the VAE decoder's / encoder's single 512-channel attention head (diffusers AutoencoderKL mid-block
  * `Attention`, reached from modules/model_k_diffusion.py:291-299 `decode_latents` and :600-606 `vae.encode`): too wide for

@@ -476,6 +476,41 @@ def test_linear_library_bias_residual(ops, M, N, K):
     assert torch.equal(yg, y)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 1280, 5120), (128, 1280, 5120), (128, 1280, 2560), (512, 1280, 1920), (300, 64, 1984),
+                                   (2048, 640, 2560)])
+def test_linear_splitk(ops, M, N, K):
+    """dsc_linear_splitk_f16 (the few-row long-K projections that went to hipBLASLt until round 3): vs the fp32 product, every
+    split count gives the un-split kernel's result up to the order of the fp32 partial sums, bit-reproducible, capturable, and
+    ops.linear takes this route for M <= 512 / K >= 1920 with the library off"""
+    g = torch.Generator().manual_seed(M + N + K + 3)
+    x = torch.randn(M, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.2).half().cuda()
+    r = torch.randn(M, N, generator=g).half().cuda()
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    one = ops.linear(x, w, b, residual=r, prefer_kernel=True) if M > 512 or K < 1920 else None
+    for sp in (0, 1, 2, 3, 5, 8, 64):
+        y = ops.linear_splitk(x, w, b, r, splits=sp)
+        assert torch.all((y.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3), (sp, (y.float() - ref).abs().max().item())
+        assert torch.equal(y, ops.linear_splitk(x, w, b, r, splits=sp))
+        if sp == 1 and one is not None:
+            assert torch.equal(y, one)                                       # one split IS dsc_linear_f16
+    y0 = ops.linear_splitk(x, w, None, None)
+    assert torch.all((y0.float() - (ref - b.float() - r.float())).abs() <= 1.5e-3 * ref.abs() + 2e-3)
+    if M <= 512 and K >= 1920 and not ops.USE_LIBRARY_GEMM:
+        assert torch.equal(ops.linear(x, w, b, residual=r), ops.linear_splitk(x, w, b, r))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            ops.linear_splitk(x, w, b, r)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            yg = ops.linear_splitk(x, w, b, r)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, ops.linear_splitk(x, w, b, r))
+
+
 @pytest.mark.parametrize("M,C,N,geglu", [(8192, 320, 960, False), (2048, 640, 640, False), (8192, 320, 2560, True),
                                           (1100, 64, 128, False), (2048, 640, 5120, True), (512, 1280, 3840, False)])
 def test_linear_layernorm_folding(ops, M, C, N, geglu):
@@ -1473,8 +1508,18 @@ def test_prompt_string_pipeline(ops):
     assert torch.isfinite(c).all() and (c - a).abs().max().item() > 1e-3
 
 
-def test_library_gemms_on_two_streams_finish_and_need_no_workspace(ops):
-    """The recorded two-stream hang (round 1: every hipBLASLt candidate timed as a concurrent pair on two streams) came from
+@pytest.fixture
+def library_routing(ops):
+    """ops.linear with the round-2 routing (few-row / long-K GEMMs to hipBLASLt): off by default since round 3"""
+    saved = (ops.USE_LIBRARY_GEMM, ops.USE_LT_RESIDUAL, ops.USE_LT_ALL)
+    ops.USE_LIBRARY_GEMM = ops.USE_LT_RESIDUAL = ops.USE_LT_ALL = True
+    yield ops
+    ops.USE_LIBRARY_GEMM, ops.USE_LT_RESIDUAL, ops.USE_LT_ALL = saved
+
+
+def test_library_gemms_on_two_streams_finish_and_need_no_workspace(library_routing):
+    """(The library is no longer in the step - every linear runs on the package's own kernels - but dsc_linear_lt_f16 stays as a
+    non-default fallback, DSC_LIBRARY_GEMM=1, and keeps its guarantees.)  The recorded two-stream hang (round 1: every hipBLASLt candidate timed as a concurrent pair on two streams) came from
     stream-K / split-K algorithms whose workgroups spin on partial tiles of workgroups that a second stream's kernels keep
     from being scheduled.  dsc_linear_lt_f16 only admits workspace-free algorithms (each workgroup owns its output tiles: no
     inter-workgroup wait, live under any residency).  Here: two host threads push every library-GEMM shape of the SD1.5 step
@@ -1483,6 +1528,7 @@ def test_library_gemms_on_two_streams_finish_and_need_no_workspace(ops):
     import ctypes
     import threading
     from diffusionspatialcontrol_amd import _lib
+    ops = library_routing
     shapes = [(512, 1280, 5120), (2048, 640, 2560), (8192, 320, 1280), (512, 1280, 2560), (512, 1280, 1920), (128, 1280, 1280),
               (128, 1280, 5120), (128, 1280, 2560), (2048, 640, 1920), (2048, 640, 1280), (8192, 320, 960)]
     g = torch.Generator().manual_seed(9)

@@ -88,11 +88,18 @@ for (M, N, K, res, geglu), cnt in shapes.items():
     t_lt = cold(run_lt, x)
     tn_ok = K % 64 == 0 and N % 64 == 0 and (not geglu or (N // 2) % 32 == 0)
     t_tn = cold(run_tn, x) if tn_ok else float("nan")
+    t_sk = {}
+    if tn_ok and not geglu and K >= 1280:                     # split-K (dsc_linear_splitk_f16): auto and forced split counts
+        ref = torch.nn.functional.linear(x.float(), w.float(), b.float()) + (r.float() if res else 0)
+        for sp in (0, 2, 4, 8):
+            t_sk[sp] = cold(lambda: ops.linear_splitk(x, w, b, r, splits=sp), x)
+        got = ops.linear_splitk(x, w, b, r).float()
+        assert (got - ref).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-2, (got - ref).abs().max().item()
     now = "gemm_tn" if ops.linear_kernel_covers(M, N, K, torch.float16, geglu) else "library"
     t_now = t_tn if now == "gemm_tn" else t_lt
     t_best = min(t_lt, t_tn) if tn_ok else t_lt
     tot_now += cnt * t_now
     tot_best += cnt * t_best
     flag = "" if t_now <= t_best * 1.03 else "   <-- other path faster"
-    print(f"{M:6d} {N:6d} {K:5d} {int(res):3d} {int(geglu):5d} {cnt:7d} | {t_lt:8.1f} {t_tn:8.1f}               | {now}{flag}", flush=True)
+    print(f"{M:6d} {N:6d} {K:5d} {int(res):3d} {int(geglu):5d} {cnt:7d} | {t_lt:8.1f} {t_tn:8.1f}               | {now}{flag}  splitK auto/2/4/8: {' '.join(f'{v:5.1f}' for v in t_sk.values())}", flush=True)
 print(f"per step: current dispatch {tot_now / 1e3:.3f} ms, per-shape best {tot_best / 1e3:.3f} ms")
