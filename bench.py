@@ -364,10 +364,14 @@ def main():
     pipe = StableDiffusionPipeline(vae, None, tok, unet, SD15Scheduler())
     n_img = a.images_per_gpu
     my_images = shard_image_indices(n_img * world, rank, world)
-    lat = torch.stack([torch.randn(4, a.size // 8, a.size // 8, generator=torch.Generator().manual_seed(1000 + i))
-                       for i in my_images]).half().to(dev)
+    def start_latents(indices):
+        return torch.stack([torch.randn(4, a.size // 8, a.size // 8, generator=torch.Generator().manual_seed(1000 + i))
+                            for i in indices]).half().to(dev)
 
-    def generate(slot=0):
+    lat = lat_mine = start_latents(my_images)
+
+    def generate(slot=0, lat=None):
+        lat = lat_mine if lat is None else lat
         out = pipe.txt2img(None, height=a.size, width=a.size, num_inference_steps=a.denoise_steps, guidance_scale=7.5,
                            latents=lat, output_type="latent", region_map_state=state, sampler_name="sample_dpmpp_2m",
                            sampler_opt={"scheduler": "karras"}, prompt_embeds=emb[1:2], negative_prompt_embeds=emb[0:1],
@@ -485,6 +489,20 @@ def main():
         names = [me]
     if res is not None:
         res["config"]["devices"] = names
+    if dist and not a.decode:
+        # per-image equality across ranks: every rank hashes the final latents of its images (one generation
+        # at a time, latency rules); rank 0 generates EVERY rank's images itself and compares - the same bits are expected since
+        # no kernel of the step is chosen per process any more (no library GEMM) and every kernel is bit-reproducible
+        import hashlib
+        ops.set_tuning_profile("latency" if a.tuning_profile == "auto" else a.tuning_profile)
+        mine = hashlib.sha256(generate(0).float().cpu().numpy().tobytes()).hexdigest()
+        hashes = [None] * world
+        td.all_gather_object(hashes, mine)
+        if res is not None:
+            own = [hashlib.sha256(generate(0, start_latents(shard_image_indices(n_img * world, r_, world))).float().cpu().numpy().tobytes()).hexdigest()
+                   for r_ in range(world)]
+            res["config"]["ranks_equal_single_process"] = bool(own == hashes)
+        td.barrier()
     if nfl > 1:
         # the launch rules for generations that SHARE the chip (include/dsc_hip.h, dsc_set_tuning_profile): the legs above ran
         # under "latency"; every slot re-captures its step under "throughput" here, outside the timed region

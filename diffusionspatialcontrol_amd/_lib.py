@@ -91,6 +91,13 @@ _SIGNATURES = {
     "dsc_linear_splitk_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "dsc_linear_splitk_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                               [ctypes.c_int, _vp, ctypes.c_size_t, ctypes.c_int, _vp]),
+    "dsc_conv3x3_gn_rows": (ctypes.c_int, [ctypes.c_int] * 7),
+    "dsc_conv3x3_gn_nhwc_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, _vp, _vp] + [ctypes.c_int] * 5 + [ctypes.c_int64] * 3 +
+                                [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "dsc_linear_gn_rows": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "dsc_linear_gn_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
+                          [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "dsc_groupnorm_apply_nhwc": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_softmax_rows_f16": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_float,
                                             ctypes.c_int, _vp]),
 }

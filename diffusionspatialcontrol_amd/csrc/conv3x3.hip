@@ -22,6 +22,7 @@
 //   epilogue   through an fp32 LDS stage: + bias (+ residual), one fp16 rounding, 128-byte row segments
 #include "dsc_common.h"
 #include "dsc_hip.h"
+#include "gn_partials.h"
 #include <type_traits>
 
 extern int g_dsc_tuning_profile;     // c_api.hip
@@ -59,6 +60,10 @@ struct ConvParams {
     long long npix;
     unsigned x_bytes, w_bytes;    // extents for the buffer descriptors
     long long* stamps;            // diagnostics (dsc_debug_set_conv_stamps): 8 x int64 per workgroup, NULL in normal calls
+    // dsc_conv3x3_gn_nhwc_f16: a per-IMAGE bias row add[b][c] (the ResNet block's time-embedding term) and the GroupNorm
+    // partial sums of the stored tensor (gn_partials.h) - 16-wide tiles, no split, Cout % 64 == 0 only
+    const half_t* add; long long add_ld;
+    float* gn_part; int gn_cpg, gn_G;
 };
 
 // LDS-DMA of 16 bytes per lane through a buffer descriptor: lanes whose offset lies beyond the extent deposit zeros -
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
             }
             __syncthreads();                                 // the epilogue's two workgroup barriers
             __syncthreads();
+            if (p.gn_part) dsc_gn::gn_tile_partials_barriers();
             return;
         }
     }
@@ -357,6 +363,9 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
     h8_t bpre = {0, 0, 0, 0, 0, 0, 0, 0};                           // bias of this thread's chunk column (the same in all four passes)
     if (p.bias && p.splits == 1 && !p.nchw && n0 + (int)(threadIdx.x & 7) * 8 + 8 <= p.Cout)
         bpre = *reinterpret_cast<const h8_t*>(p.bias + n0 + (threadIdx.x & 7) * 8);
+    h8_t apre = {0, 0, 0, 0, 0, 0, 0, 0};                          // per-image bias row (gn entry: TW = 16, one image per tile)
+    if (p.add && ob[0] >= 0) apre = *reinterpret_cast<const h8_t*>(p.add + (long long)ob[0] * p.add_ld + n0 + (threadIdx.x & 7) * 8);
+    float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int cidx = 0; cidx < 4; ++cidx) {
         rpre[cidx] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
@@ -408,7 +417,11 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
                 const h8_t bv = bpre, rv = rpre[cidx];
                 h8_t o;
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)rv[jj]);
+                for (int jj = 0; jj < 8; ++jj) {
+                    o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)apre[jj] + (float)rv[jj]);
+                    const float f = (float)o[jj];                    // statistics of the fp16 tensor the GroupNorm will read
+                    gs[jj] += f; gq[jj] += f * f;
+                }
                 *reinterpret_cast<h8_t*>(p.out + gp * p.ldo + c0) = o;
             } else {
                 // few output channels (conv_out) and / or channel-major output: element-wise
@@ -426,6 +439,11 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
                 }
             }
         }
+    }
+    if (p.gn_part) {
+        // this tile's (group, part) sums of what it stored: tile bm = sub-block bm (TW = 16) = pixel tile bm % bpi of image ob[0]
+        float* dst = ob[0] >= 0 ? p.gn_part + ((long long)ob[0] * p.bpi + (bm - ob[0] * p.bpi)) * p.gn_G * 4 : nullptr;
+        dsc_gn::gn_tile_partials(gs, gq, reinterpret_cast<float*>(smem) + BM * kEpiStride, n0, p.gn_cpg, p.gn_G, dst);
     }
     if (p.stamps && threadIdx.x == 0) {
         unsigned hwid;
@@ -546,10 +564,50 @@ extern "C" size_t dsc_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int 
     return p.splits > 1 ? (size_t)p.splits * p.npix * Cout * sizeof(float) : 0;
 }
 
+namespace {
+struct GnArgs { const void* add; int64_t add_ld; float* part; int groups; };
+int conv_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
+              int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
+              int resample, int out_nchw, int splits, int dtype, void* workspace, size_t workspace_bytes, void* stream,
+              const GnArgs* gn);
+}
+
 extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                                     int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
                                     int resample, int out_nchw, int splits, int dtype, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+    return conv_impl(x, w, bias, residual, out, B, H, W, Cin, Cout, ldx, ldr, ldo, resample, out_nchw, splits, dtype, workspace,
+                     workspace_bytes, stream, nullptr);
+}
+
+// partial rows per image (pixel tiles of 8 x 16) when the GroupNorm-statistics form covers the shape, else 0: 16-wide tiles, no
+// split chosen by the cost model (a split convolution's output is rounded by the reduce launch), whole 64-channel tiles,
+// groups of at most 64 channels, at most 128 partial rows per image
+extern "C" int dsc_conv3x3_gn_rows(int B, int H, int W, int Cin, int Cout, int groups, int resample) {
+    ConvParams p{};
+    const int Hc = H, Wc = W;
+    if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cout % BN != 0 || Cout % groups != 0 || Cout / groups > 64) return 0;
+    if (resample == DSC_CONV_STRIDE2 || resample == DSC_CONV_STRIDE2_PAD_BR) return 0;   // (the kept pixels are a quarter of a tile's)
+    if (plan(B, Hc, Wc, Cin, Cout, 0, &p) != 16 || p.splits != 1 || p.bpi > 128) return 0;
+    return p.bpi;
+}
+
+extern "C" int dsc_conv3x3_gn_nhwc_f16(const void* x, const void* w, const void* bias, const void* add, int64_t add_ld,
+                                       const void* residual, void* out, int B, int H, int W, int Cin, int Cout, int64_t ldx,
+                                       int64_t ldr, int64_t ldo, int resample, float* gn_part, int groups, int dtype, void* stream) {
+    if (!gn_part || groups <= 0) return DSC_ERR_BAD_ARG;
+    if (!dsc_conv3x3_gn_rows(B, H, W, Cin, Cout, groups, resample)) return DSC_ERR_UNSUPPORTED;
+    if (add && (add_ld < Cout || add_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(add) & 15))) return DSC_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(gn_part) & 7) return DSC_ERR_UNSUPPORTED;
+    const GnArgs gn{add, add_ld, gn_part, groups};
+    return conv_impl(x, w, bias, residual, out, B, H, W, Cin, Cout, ldx, ldr, ldo, resample, 0, 1, dtype, nullptr, 0, stream, &gn);
+}
+
+namespace {
+int conv_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
+              int B, int H, int W, int Cin, int Cout, int64_t ldx, int64_t ldr, int64_t ldo,
+              int resample, int out_nchw, int splits, int dtype, void* workspace, size_t workspace_bytes, void* stream,
+              const GnArgs* gn) {
     if (!x || !w || !out || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
     if (ldx < Cin || (!out_nchw && ldo < Cout) || (residual && ldr < Cout)) return DSC_ERR_BAD_ARG;
@@ -565,6 +623,10 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     p.out = static_cast<half_t*>(out); p.ws = static_cast<float*>(workspace);
     p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
     p.stamps = g_conv_stamps;
+    if (gn) {
+        p.add = static_cast<const half_t*>(gn->add); p.add_ld = gn->add_ld;
+        p.gn_part = gn->part; p.gn_G = gn->groups; p.gn_cpg = Cout / gn->groups;
+    }
     // activation-heavy shapes (the 64x64 level): a pixel tile's halo is fetched into one L2 for all of its channel blocks
     // (640->320 @64x64 66.8 -> 61.5 us in the step); weight-heavy ones keep sharing the weight slab
     p.order = g_conv_order >= 0 ? g_conv_order : (p.npix >= 2ll * Cout ? 1 : 0);
@@ -624,3 +686,4 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
     }
     return DSC_OK;
 }
+}  // namespace

@@ -28,6 +28,7 @@
 //     fp16 stores are full 128-byte row segments instead of 8-byte column-strided pieces; ONE fp16 rounding.
 #include "dsc_common.h"
 #include "dsc_hip.h"
+#include "gn_partials.h"
 
 extern int g_dsc_tuning_profile;     // c_api.hip
 
@@ -62,6 +63,9 @@ struct GemmParams {
     // of cold weights out of HBM quickly, four to eight times as many workgroups can.
     int splits, kps, tiles;
     float* ws;
+    // dsc_linear_gn_f16: GroupNorm partial sums of the stored tensor (gn_partials.h): rows are pixels, gn_L of them per image
+    // (gn_L % BM == 0: a row tile lies in one image), 64-column tiles only
+    float* gn_part; int gn_cpg, gn_G, gn_L;
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             }
             __syncthreads();                                 // the epilogue's two workgroup barriers
             __syncthreads();
+            if (p.gn_part) dsc_gn::gn_tile_partials_barriers();
             return;
         }
     } else {
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             }
             return;
         }
+        float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                     o[j] = (half_t)(a + (float)bv[j] + (float)rv[j]);
                     const float f = (float)o[j];                 // statistics of the fp16 row, as the LayerNorm kernel takes them
                     s1 += f; s2 += f * f;
+                    gs[j] += f; gq[j] += f * f;                  // ... and per channel over this thread's rows, for a GroupNorm
                 }
                 if (scat) {
                     int bb = kv_b0, ll = kv_l0 + row;
@@ -373,6 +380,13 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                     float* dst = p.ln_out + ((long long)(m0 + row) * (nb * NT) + bn * NT + (ch >> 3)) * 2;
                     dst[0] = s1; dst[1] = s2;
                 }
+            }
+        }
+        if constexpr (NT == 1) {
+            if (p.gn_part) {                                      // row tile bm = pixel tile (m0 % gn_L) / BM of image m0 / gn_L
+                const int gb = m0 / p.gn_L, gpt = (m0 - gb * p.gn_L) / BM;
+                float* dst = p.gn_part + ((long long)gb * (p.gn_L / BM) + gpt) * p.gn_G * 4;
+                dsc_gn::gn_tile_partials(gs, gq, stage + BM * kES + 2 * BM, n0, p.gn_cpg, p.gn_G, dst);
             }
         }
     }
@@ -436,10 +450,13 @@ extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, co
 }
 
 namespace {
+struct GnArgs { float* part; int groups; int rows_per_image; };
 int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
-                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits = 1, float* ws = nullptr);
+                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits = 1, float* ws = nullptr,
+                const GnArgs* gn = nullptr);
+int gemm_tile_rows(int64_t M, int N, bool geglu);
 }
 
 extern "C" int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
@@ -464,7 +481,7 @@ namespace {
 int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
-                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits, float* ws) {
+                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits, float* ws, const GnArgs* gn) {
     if ((ln_in && (!ln_cvec || ln_nb <= 0)) || (ln_out && geglu)) return DSC_ERR_BAD_ARG;
     if (ln_in && !al16(ln_cvec)) return DSC_ERR_UNSUPPORTED;       // read as float4 pairs
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
@@ -498,11 +515,15 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // Tile height: 64 token rows when 128-row tiles would leave the chip half empty (fewer than 192 workgroups - the 16x16
     // level's C->C GEMMs: M = 512, N = 1280 -> 80 workgroups walking 20 K tiles each) and the rows allow it; GEGLU keeps 128.
     int nb = N / BN;
-    int bm = 128;
+    int bm = gemm_tile_rows(M, N, geglu != 0);
+    if (gn) {
+        if (geglu || kv_out || splits > 1 || N % gn->groups != 0 || N / gn->groups > 64 || gn->rows_per_image % bm != 0 ||
+            M % gn->rows_per_image != 0)
+            return DSC_ERR_UNSUPPORTED;
+        p.gn_part = gn->part; p.gn_G = gn->groups; p.gn_cpg = N / gn->groups; p.gn_L = gn->rows_per_image;
+    }
     // (measured, tools/mb_gemm.py: M=512 N=1280 K=1280 11.8 -> 8.1 us, M=8192 N=320 K=320 9.1 -> 7.5, M=8192 N=320 K=1280 24.4 ->
     // 20.7; at 480+ workgroups of 128 rows the taller tile wins: M=2048 N=1920 K=640 12.3 vs 13.5)
-    if (!geglu && (long long)((M + 127) / 128) * nb <= 320 && g_gemm_bm != 128) bm = 64;
-    if (g_gemm_bm == 64 && !geglu) bm = 64;
     const int mb = (int)((M + bm - 1) / bm);
     // 3 stages = 72 KiB -> two workgroups per CU.  A deeper ring (6 stages) was measured and changes nothing: a K tile
     // costs ~1000 cycles because a CU ingests only ~24 B/cycle from L2 (24 KiB per tile), not because of DMA latency -
@@ -550,7 +571,8 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     }
     // the fp32 epilogue stage (bm x 68 floats + the row statistics) reuses the ring
     size_t lds = (size_t)stages * stage_halves(bm) * sizeof(half_t);
-    const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float);
+    const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float) +
+                       (gn ? (size_t)dsc_gn::kScratchFloats * sizeof(float) : 0);
     if (lds < epi) lds = epi;
     // Four DMA-only loader waves beside the four computing ones: in the step 1-3 % on the 64-row-tile GEMMs (10.7 -> 10.6,
     // 9.6 -> 9.3, 8.9 -> 8.7 us; 5-20 % back to back with warm weights, tools/chk_gemm_loader.py), while the 128-row tiles
@@ -576,6 +598,36 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 }  // namespace
+
+namespace {
+// tile height: 64 token rows when 128-row tiles would leave the chip half empty (see linear_impl); GEGLU keeps 128
+int gemm_tile_rows(int64_t M, int N, bool geglu) {
+    int bm = 128;
+    if (!geglu && (long long)((M + 127) / 128) * (N / BN) <= 320 && g_gemm_bm != 128) bm = 64;
+    if (g_gemm_bm == 64 && !geglu) bm = 64;
+    return bm;
+}
+}  // namespace
+
+// partial rows per image of dsc_linear_gn_f16 (row tiles per image), 0 when the shape is not covered
+extern "C" int dsc_linear_gn_rows(int64_t M, int N, int K, int rows_per_image, int groups) {
+    if (M <= 0 || N <= 0 || K <= 0 || rows_per_image <= 0 || groups <= 0 || K % BK != 0 || N % BN != 0 || N % groups != 0 ||
+        N / groups > 64 || M % rows_per_image != 0)
+        return 0;
+    const int bm = gemm_tile_rows(M, N, false);
+    if (rows_per_image % bm != 0 || rows_per_image / bm > 128) return 0;
+    return rows_per_image / bm;
+}
+
+extern "C" int dsc_linear_gn_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int rows_per_image,
+                                 float* gn_part, int groups, int dtype, void* stream) {
+    if (!gn_part || (reinterpret_cast<uintptr_t>(gn_part) & 7)) return DSC_ERR_BAD_ARG;
+    if (!dsc_linear_gn_rows(M, N, K, rows_per_image, groups)) return DSC_ERR_UNSUPPORTED;
+    const GnArgs gn{gn_part, groups, rows_per_image};
+    return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldr, ldo, 0, nullptr, 0, nullptr, 0.f, nullptr, dtype, stream,
+                       nullptr, 0, 0, 1, nullptr, &gn);
+}
 
 // K tiles per split: as many splits as bring the grid to ~512 workgroups, at least 8 K tiles each
 static int splitk_auto(int64_t M, int N, int K) {

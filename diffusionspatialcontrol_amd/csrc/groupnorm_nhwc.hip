@@ -34,6 +34,9 @@ struct GnN {
     // concatenation mode (dsc_groupnorm_silu_nhwc_cat): the input is the channel concatenation [x | x2] (C1 channels from
     // x, C - C1 from x2) that was never materialised; the pass that reads the sources also writes it to `cat`
     const half_t* x2; half_t* cat; int C1;
+    // statistics from the PRODUCER of x (dsc_groupnorm_apply_nhwc; gn_partials.h): fpart[b][pt][g][which][2] fp32, fPT pixel
+    // tiles per image - the apply pass is then the whole GroupNorm
+    const float* fpart; int fPT;
 };
 
 // element (b, pix, channel c .. c+7) of the input; in concatenation mode read from the source that holds c and copied to cat
@@ -162,11 +165,19 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
     const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
     double pl1[kPL], pl2[kPL];
+    // producer partials: group g's sums over pixel tile i are slot (g, 0) plus, when the group straddles a 64-channel tile
+    // boundary, slot (g, 1) (gn_partials.h); thread (g, part) takes tiles part, part + P, ... in order
+    const bool straddles = p.fpart && (g * p.cpg) / 64 != ((g + 1) * p.cpg - 1) / 64;
+    const float* fsrc = p.fpart ? p.fpart + ((long long)b * p.fPT * p.G + g) * 4 : nullptr;
+    f4x_t fp[kPL];
 #pragma unroll
     for (int u = 0; u < kPL; ++u) {
         const int i = part + u * P;
         pl1[u] = 0.0; pl2[u] = 0.0;
-        if (p.inline_stats && part < P && i < p.nchunk) { pl1[u] = src[(long long)i * p.G * 2]; pl2[u] = src[(long long)i * p.G * 2 + 1]; }
+        fp[u] = f4x_t{0.f, 0.f, 0.f, 0.f};
+        if (p.fpart) {
+            if (part < P && i < p.fPT) fp[u] = *reinterpret_cast<const f4x_t*>(fsrc + (long long)i * p.G * 4);
+        } else if (p.inline_stats && part < P && i < p.nchunk) { pl1[u] = src[(long long)i * p.G * 2]; pl2[u] = src[(long long)i * p.G * 2 + 1]; }
     }
     const h8_t ga = *reinterpret_cast<const h8_t*>(p.gamma + c8 * 8);
     const h8_t be = *reinterpret_cast<const h8_t*>(p.beta + c8 * 8);
@@ -182,9 +193,22 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     if (p.inline_stats) {
         if (part < P) {
             double a1 = 0.0, a2 = 0.0;
+            if (p.fpart) {
 #pragma unroll
-            for (int u = 0; u < kPL; ++u) { a1 += pl1[u]; a2 += pl2[u]; }         // (missing chunks add zero)
-            for (int i = part + kPL * P; i < p.nchunk; i += P) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+                for (int u = 0; u < kPL; ++u) {                                   // (missing tiles add zero)
+                    a1 += (double)fp[u][0]; a2 += (double)fp[u][1];
+                    if (straddles) { a1 += (double)fp[u][2]; a2 += (double)fp[u][3]; }
+                }
+                for (int i = part + kPL * P; i < p.fPT; i += P) {
+                    const f4x_t v = *reinterpret_cast<const f4x_t*>(fsrc + (long long)i * p.G * 4);
+                    a1 += (double)v[0]; a2 += (double)v[1];
+                    if (straddles) { a1 += (double)v[2]; a2 += (double)v[3]; }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kPL; ++u) { a1 += pl1[u]; a2 += pl2[u]; }         // (missing chunks add zero)
+                for (int i = part + kPL * P; i < p.nchunk; i += P) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
+            }
             red[(part * 64 + g) * 2] = a1; red[(part * 64 + g) * 2 + 1] = a2;
         }
         __syncthreads();
@@ -595,3 +619,21 @@ int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, con
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
 }  // namespace
+
+// The GroupNorm whose statistics came out of the producing kernel's epilogue (gn_partials.h): ONE launch
+extern "C" int dsc_groupnorm_apply_nhwc(const void* x, void* y, const void* gamma, const void* beta, const float* gn_part,
+                                        int part_rows, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                                        void* stream) {
+    if (!x || !y || !gamma || !beta || !gn_part || part_rows <= 0 || B <= 0 || C <= 0 || hw <= 0 || groups <= 0) return DSC_ERR_BAD_ARG;
+    if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
+    GnN p{};
+    p.B = B; p.C = C; p.HW = hw; p.G = groups;
+    if (!plan(p) || p.cpg > 64 || C % 64 != 0) return DSC_ERR_UNSUPPORTED;
+    if (!al16(x) || !al16(y) || !al16(gamma) || !al16(beta) || !al16(gn_part)) return DSC_ERR_UNSUPPORTED;
+    p.x = static_cast<const half_t*>(x); p.y = static_cast<half_t*>(y);
+    p.gamma = static_cast<const half_t*>(gamma); p.beta = static_cast<const half_t*>(beta);
+    p.eps = eps; p.silu = apply_silu;
+    p.fpart = gn_part; p.fPT = part_rows; p.inline_stats = 1;
+    DSC_LAUNCH(gn_nhwc_apply, dim3(B * p.anchunk), dim3(p.cv * p.k), 0, static_cast<hipStream_t>(stream), p);
+    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
+}

@@ -292,6 +292,19 @@ def _image(t, h, w):
     return t.reshape(b, h, w, c).permute(0, 3, 1, 2)
 
 
+# GroupNorm statistics from the producer's epilogue (ops.conv3x3_gn / ops.linear_gn): asked for where the GroupNorm that follows
+# is a two-launch one - the 64x64 / 32x32 levels at batch 1 (smaller tensors have a one-launch GroupNorm already, and their
+# convolutions are split over K)
+GN_FUSE_MIN_ROWS = 1024
+
+
+def _with_gn(img, part):
+    """attach a producer's GroupNorm partial sums to the tensor OBJECT handed on (GroupNormAct.forward looks for them)"""
+    if part is not None:
+        img._dsc_gn = part
+    return img
+
+
 class Conv1x1(nn.Conv2d):
     """1x1 convolution run as a token-major GEMM (hipBLASLt) instead of a MIOpen convolution: same parameters and
     state_dict keys as nn.Conv2d(cin, cout, 1).  With channels-last activations the [B, h*w, C] token view is free,
@@ -301,8 +314,16 @@ class Conv1x1(nn.Conv2d):
     def __init__(self, cin, cout):
         super().__init__(cin, cout, 1)
 
-    def tokens(self, t, bias=None, residual=None):
-        return ops.linear(t, self.weight.flatten(1), self.bias if bias is None else bias, residual=residual)
+    def tokens(self, t, bias=None, residual=None, gn_groups=0):
+        """gn_groups > 0: also try to get the GroupNorm partial sums of the result out of the GEMM's epilogue (for the
+        GroupNorm that reads it next) -> (tokens, ops.GnPartials | None)"""
+        b = self.bias if bias is None else bias
+        if gn_groups and t.dim() == 3 and t.shape[0] * t.shape[1] >= GN_FUSE_MIN_ROWS:
+            got = ops.linear_gn(t, self.weight.flatten(1), b, residual, t.shape[1], gn_groups)
+            if got is not None:
+                return got
+        y = ops.linear(t, self.weight.flatten(1), b, residual=residual)
+        return (y, None) if gn_groups else y
 
     def forward(self, x, residual=None):
         b, c, h, w = x.shape
@@ -318,6 +339,11 @@ class GroupNormAct(nn.GroupNorm):
         self.act = act
 
     def forward(self, x, add=None):
+        part = ops.gn_partials_of(x) if add is None and x.dim() == 4 else None
+        if part is not None and part.groups == self.num_groups and part.C == x.shape[1] and part.B == x.shape[0] \
+                and part.hw == x.shape[2] * x.shape[3] and x.is_contiguous(memory_format=torch.channels_last):
+            # the kernel that wrote x also emitted its group sums: the whole GroupNorm is one launch
+            return ops.groupnorm_apply_nhwc(x, part, self.num_groups, self.weight, self.bias, self.eps, self.act)
         return ops.groupnorm_silu_nhwc(x, self.num_groups, self.weight, self.bias, self.eps, self.act, add=add)
 
     def of_cat(self, x1, x2):
@@ -517,9 +543,9 @@ class Transformer2DModel(nn.Module):
             res = res.repeat(t.shape[0] // res.shape[0], 1, 1)
         if self.use_linear_projection:
             t = ops.linear(t, self.proj_out.weight, self.proj_out.bias, residual=res)
-        else:
-            t = self.proj_out.tokens(t, residual=res)
-        return _image(t, h, w)
+            return _image(t, h, w)
+        t, part = self.proj_out.tokens(t, residual=res, gn_groups=self.norm.num_groups)   # (+ the next GroupNorm's statistics)
+        return _with_gn(_image(t, h, w), part)
 
 
 def _conv3x3(x, weight, bias=None, residual=None):
@@ -556,16 +582,26 @@ class ResnetBlock2D(nn.Module):
             h, x = self.norm1.of_cat(*x)
         else:
             h = self.norm1(x)
-        h = _conv3x3(h, self.conv1.weight)
         if temb_add is None:
             temb_add = F.linear(temb_act, self.time_emb_proj.weight, self.temb_bias())
+        g = self.norm2.num_groups
+        fuse = h.is_cuda and h.dtype == torch.float16 and h.shape[0] * h.shape[2] * h.shape[3] >= GN_FUSE_MIN_ROWS
+        if fuse and ops.conv3x3_gn_rows(h, self.conv1.weight, g) > 0:
+            # conv1 adds the time-embedding row itself (diffusers: hidden_states + temb between conv1 and norm2) and emits norm2's
+            # statistics: norm2 is one launch
+            h = self.norm2(ops.conv3x3_gn(h, self.conv1.weight, g, add=temb_add[:h.shape[0]]))
+        else:
+            h = self.norm2(_conv3x3(h, self.conv1.weight), add=temb_add)
         if self.conv_shortcut is None:
-            return _conv3x3(self.norm2(h, add=temb_add), self.conv2.weight, self.conv2.bias, residual=x)
-        h = _conv3x3(self.norm2(h, add=temb_add), self.conv2.weight)
+            if fuse and ops.conv3x3_gn_rows(h, self.conv2.weight, g) > 0:       # ... and conv2 the NEXT GroupNorm's (same grouping)
+                return ops.conv3x3_gn(h, self.conv2.weight, g, bias=self.conv2.bias, residual=x)
+            return _conv3x3(h, self.conv2.weight, self.conv2.bias, residual=x)
+        h = _conv3x3(h, self.conv2.weight)
         b = _derived(self, "sb", (self.conv_shortcut.bias, self.conv2.bias),
                      lambda: (self.conv_shortcut.bias + self.conv2.bias).contiguous())
         bsz, _, hh, ww = h.shape
-        return _image(self.conv_shortcut.tokens(_tokens(x), bias=b, residual=_tokens(h)), hh, ww)
+        t, part = self.conv_shortcut.tokens(_tokens(x), bias=b, residual=_tokens(h), gn_groups=g)
+        return _with_gn(_image(t, hh, ww), part)
 
 
 class Downsample2D(nn.Module):

@@ -324,6 +324,126 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
     return y
 
 
+USE_GN_FUSE = os.environ.get("DSC_GN_FUSE", "1") != "0"   # GroupNorm statistics from the producing convolution / GEMM epilogue (gn_partials.h)
+
+
+class GnPartials:
+    """the GroupNorm partial sums a producer emitted for the tensor it wrote (dsc_conv3x3_gn_nhwc_f16 / dsc_linear_gn_f16):
+    buffer fp32 [B, rows, groups, 2, 2], for a tensor of C channels normalised in `groups` groups"""
+    __slots__ = ("buf", "rows", "groups", "C", "B", "hw")
+
+    def __init__(self, buf, rows, groups, C, B, hw):
+        self.buf, self.rows, self.groups, self.C, self.B, self.hw = buf, rows, groups, C, B, hw
+
+
+def gn_partials_of(t):
+    """the GnPartials a producer attached to the tensor OBJECT it returned (views and copies carry none), or None"""
+    return getattr(t, "_dsc_gn", None) if USE_GN_FUSE else None
+
+
+def groupnorm_apply_nhwc(x, part, groups, weight, bias, eps, act):
+    """GroupNorm [+ SiLU] in ONE launch from the producer's partial sums (dsc_groupnorm_apply_nhwc); x channels_last [B,C,h,w]"""
+    _require_gpu(x)
+    B, C, h, w = x.shape
+    if part.groups != groups or part.C != C or part.B != B or part.hw != h * w or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("groupnorm_apply_nhwc: the partial sums do not belong to this tensor / grouping")
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    rc = _lib.load_library().dsc_groupnorm_apply_nhwc(_p(x), _p(y), _p(weight), _p(bias), _p(part.buf), part.rows, B, C, h * w,
+                                                      groups, float(eps), 1 if act else 0, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_groupnorm_apply_nhwc")
+    return y
+
+
+def conv3x3_gn_rows(x, weight, groups, upsample=False):
+    """pixel tiles per image when dsc_conv3x3_gn_nhwc_f16 covers this convolution (and GroupNorm grouping of its output), else 0"""
+    if not (USE_GN_FUSE and conv3x3_supported(x, weight, upsample=upsample)):
+        return 0
+    B, C, H, W = x.shape
+    f = 2 if upsample else 1
+    return int(_lib.load_library().dsc_conv3x3_gn_rows(B, H * f, W * f, C, weight.shape[0], groups, 1 if upsample else 0))
+
+
+def conv3x3_gn(x, weight, groups, bias=None, add=None, residual=None, upsample=False):
+    """conv3x3 (+ bias) (+ per-image bias row add [B, Cout]) (+ residual), channels_last; the returned tensor carries the
+    GroupNorm partial sums of what was stored (gn_partials_of) - call only when conv3x3_gn_rows() > 0"""
+    _require_gpu(x, weight)
+    lib = _lib.load_library()
+    cl = torch.channels_last
+    if not x.is_contiguous(memory_format=cl):
+        x = x.contiguous(memory_format=cl)
+    if not weight.is_contiguous(memory_format=cl):
+        weight = weight.contiguous(memory_format=cl)
+    B, Cin, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
+    Cout = weight.shape[0]
+    rows = int(lib.dsc_conv3x3_gn_rows(B, H, W, Cin, Cout, groups, 1 if upsample else 0))
+    if rows <= 0:
+        raise ValueError("conv3x3_gn: shape not covered (ask conv3x3_gn_rows first)")
+    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+    ldr = 0
+    if residual is not None:
+        if residual.shape != out.shape:
+            raise ValueError("conv3x3_gn: residual must have the output's shape")
+        if not residual.is_contiguous(memory_format=cl):
+            residual = residual.contiguous(memory_format=cl)
+        ldr = Cout
+    add_ld = 0
+    if add is not None:
+        if add.stride(-1) != 1 or add.stride(0) % 8 != 0 or add.data_ptr() % 16 != 0:
+            add = add.contiguous()
+        add_ld = add.stride(0)
+    part = torch.empty((B, rows, groups, 2, 2), dtype=torch.float32, device=x.device)
+    rc = lib.dsc_conv3x3_gn_nhwc_f16(_p(x), _p(weight), _p(bias), _p(add), add_ld, _p(residual), _p(out), B, H, W, Cin, Cout, Cin,
+                                     ldr, Cout, 1 if upsample else 0, _p(part), groups, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_conv3x3_gn_nhwc_f16")
+    out._dsc_gn = GnPartials(part, rows, groups, Cout, B, H * W)
+    return out
+
+
+def linear_gn(x, weight, bias, residual, rows_per_image, groups):
+    """x [B, L, K] @ weight.T (+ bias) (+ residual) -> [B, L, N] with the GroupNorm partial sums of the result (a 1x1 convolution
+    in token-major form: proj_out, conv_shortcut), or None when dsc_linear_gn_f16 does not cover the shape"""
+    if not USE_GN_FUSE or not x.is_cuda or x.dtype != torch.float16 or x.dim() != 3:
+        return None
+    lib = _lib.load_library()
+    B, L, K = x.shape
+    N = weight.shape[0]
+    M = B * L
+    if L != rows_per_image or not weight.is_contiguous() or weight.dtype != torch.float16:
+        return None
+    rows = int(lib.dsc_linear_gn_rows(M, N, K, rows_per_image, groups))
+    if rows <= 0 or not linear_kernel_can(x, weight, bias, residual):
+        return None
+    x2 = x.reshape(M, K)
+    r2 = residual.reshape(M, N) if residual is not None else None
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    part = torch.empty((B, rows, groups, 2, 2), dtype=torch.float32, device=x.device)
+    rc = lib.dsc_linear_gn_f16(_p(x2), _p(weight), _p(bias), _p(r2), _p(out), M, N, K, x2.stride(0),
+                               r2.stride(0) if r2 is not None else 0, N, rows_per_image, _p(part), groups, 0, _stream_ptr(x))
+    _lib.check(rc, "dsc_linear_gn_f16")
+    return out.reshape(B, L, N), GnPartials(part, rows, groups, N, B, L)
+
+
+def linear_kernel_can(x, weight, bias, residual):
+    """dsc_linear_f16's operand constraints (not its row / K preferences): K, N multiples of 64, 16-byte aligned unit-stride rows"""
+    N, K = weight.shape
+    M = x.numel() // K
+    if not (x.dtype == torch.float16 and weight.dtype == torch.float16 and K % 64 == 0 and N % 64 == 0 and x.stride(-1) == 1
+            and weight.is_contiguous()):
+        return False
+    x2 = x.reshape(M, K)
+    if not (x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0):
+        return False
+    if bias is not None and (bias.dtype != torch.float16 or bias.data_ptr() % 16 != 0):
+        return False
+    if residual is not None:
+        r2 = residual.reshape(M, N)
+        if not (r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0):
+            return False
+    return True
+
+
 USE_GN_CAT = os.environ.get("DSC_GN_CAT", "1") != "0"   # up blocks: the skip concatenation is written by the GroupNorm that reads it
 
 

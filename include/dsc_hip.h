@@ -394,6 +394,34 @@ int dsc_add_layernorm(const void* x, const void* a, const void* gamma, const voi
 int dsc_geglu(const void* x, void* y, int64_t rows, int n, int dtype, void* stream);
 
 /*
+ * GroupNorm statistics from the PRODUCER's epilogue - the GroupNorms of the UNet's ResNet / transformer blocks
+ * (modules/u_net_condition_modify.py:465-470,1304-1306 and the diffusers blocks it builds) at the 64x64 / 32x32 levels were a
+ * statistics launch + an apply launch each, and the statistics launch re-read a tensor that the convolution / GEMM in front of it
+ * had just written.  These entries let that producer emit the statistics:
+ *   dsc_conv3x3_gn_nhwc_f16  = dsc_conv3x3_nhwc_f16 (no split, channels-last output) + `add`: an optional per-IMAGE bias row
+ *                              add[b][c] (fp16, row stride add_ld: the ResNet block's time-embedding projection, which
+ *                              diffusers adds between conv1 and norm2) + the partial sums of the fp16 tensor it stores;
+ *   dsc_linear_gn_f16        = dsc_linear_f16 (bias / residual epilogue) whose rows are the pixels of images of
+ *                              `rows_per_image` rows + the same partial sums (1x1 convolutions: proj_out, conv_shortcut);
+ *   dsc_groupnorm_apply_nhwc = the whole GroupNorm (+ SiLU) in ONE launch given those partial sums.
+ * gn_part is fp32 [B][rows][groups][2][2] with rows = dsc_*_gn_rows(...) pixel tiles per image (0 = shape not covered: 16-wide
+ * convolution tiles without split-K, Cout % 64 == 0, groups of <= 64 channels, <= 128 tiles per image); slot [g][1] holds the
+ * part of a group that lies beyond a 64-channel tile boundary.  Fixed summation orders: bit-reproducible.  No workgroup waits
+ * for another - the partial sums cross the kernel boundary.
+ */
+int dsc_conv3x3_gn_rows(int B, int H, int W, int Cin, int Cout, int groups, int resample);
+int dsc_conv3x3_gn_nhwc_f16(const void* x, const void* w, const void* bias, const void* add, int64_t add_ld,
+                            const void* residual, void* out, int B, int H, int W, int Cin, int Cout, int64_t ldx,
+                            int64_t ldr, int64_t ldo, int resample, float* gn_part, int groups, int dtype, void* stream);
+int dsc_linear_gn_rows(int64_t M, int N, int K, int rows_per_image, int groups);
+int dsc_linear_gn_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
+                      int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int rows_per_image,
+                      float* gn_part, int groups, int dtype, void* stream);
+int dsc_groupnorm_apply_nhwc(const void* x, void* y, const void* gamma, const void* beta, const float* gn_part,
+                             int part_rows, int B, int C, int hw, int groups, float eps, int apply_silu, int dtype,
+                             void* stream);
+
+/*
  * Split-K form of dsc_linear_f16 for few-row, long-K projections - out = x . w^T (+ bias) (+ residual) - the feed-forward
  * output projections (`ff.net.2`, K = 4C) and the 1x1 `conv_shortcut`s on concatenated skips (K = 1920 / 2560) of the 16x16 and
  * 8x8 UNet levels that modules/u_net_condition_modify.py builds from diffusers blocks (M = 128 / 512 token rows at batch 1).

@@ -1701,3 +1701,75 @@ def test_softmax_rows(ops, rows, n):
     assert (out.float().sum(-1).cpu() - 1).abs().max().item() < 2e-3
     again = ops.softmax_rows(sc, scale=0.37, out=sc)               # in place: each workgroup owns its row
     assert again.data_ptr() == sc.data_ptr() and torch.equal(again, out)
+
+
+@pytest.mark.parametrize("B,hw,cin,cout,groups", [(2, 64, 320, 320, 32), (2, 32, 640, 640, 32), (2, 32, 320, 640, 32), (1, 96, 320, 320, 32),
+                                                  (3, 16, 64, 128, 8), (2, 64, 64, 64, 1)])
+def test_groupnorm_statistics_from_the_convolution_epilogue(ops, B, hw, cin, cout, groups):
+    """dsc_conv3x3_gn_nhwc_f16 + dsc_groupnorm_apply_nhwc (round 3): the convolution adds the per-image bias row (the ResNet
+    block's time-embedding term), stores the same bytes as dsc_conv3x3_nhwc_f16 would for that sum, and emits per-(pixel tile,
+    group) partial sums from which the GroupNorm runs in ONE launch - against the two-launch GroupNorm of the same tensor and
+    an fp32 reference; groups that straddle the 64-channel tiles (cpg = 10, 20), 72 partial rows per image (96 x 96), bit-stable."""
+    g = torch.Generator().manual_seed(B * hw + cin + cout)
+    x = (torch.randn(B, cin, hw, hw, generator=g) * 0.7).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half().cuda().contiguous(memory_format=torch.channels_last)
+    bias = (torch.randn(cout, generator=g) * 0.2).half().cuda()
+    add = (torch.randn(B, cout, generator=g) * 0.5).half().cuda()
+    res = torch.randn(B, cout, hw, hw, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).half().cuda()
+    beta = (0.1 * torch.randn(cout, generator=g)).half().cuda()
+    rows = ops.conv3x3_gn_rows(x, w, groups)
+    if rows == 0:
+        pytest.skip("shape not covered by the statistics-emitting form (split-K convolution or 8-wide tiles)")
+    assert rows == ((hw + 7) // 8) * ((hw + 15) // 16)
+    for kw in ({"add": add}, {"bias": bias, "residual": res}, {"bias": bias, "add": add, "residual": res}, {}):
+        out = ops.conv3x3_gn(x, w, groups, **kw)
+        part = ops.gn_partials_of(out)
+        assert part is not None and part.rows == rows and tuple(part.buf.shape) == (B, rows, groups, 2, 2)
+        ref = F.conv2d(x.float(), w.float(), kw.get("bias").float() if "bias" in kw else None, padding=1)
+        if "add" in kw:
+            ref = ref + add.float()[:, :, None, None]
+        if "residual" in kw:
+            ref = ref + res.float()
+        assert torch.all((out.float() - ref).abs() <= 2e-3 * ref.abs() + 4e-3)
+        if "add" not in kw:                                    # without the per-image row: the bytes of the plain entry
+            assert torch.equal(out, ops.conv3x3(x, w, kw.get("bias"), kw.get("residual"), splits=1))
+        for act in (True, False):
+            one = ops.groupnorm_apply_nhwc(out, part, groups, gamma, beta, 1e-5, act)
+            two = ops.groupnorm_silu_nhwc(out, groups, gamma, beta, 1e-5, act)
+            gref = F.group_norm(out.float(), groups, gamma.float(), beta.float(), 1e-5)
+            gref = F.silu(gref) if act else gref
+            assert (one.float() - gref).abs().max().item() < 6e-3 and (one.float() - two.float()).abs().max().item() < 4e-3
+        again = ops.conv3x3_gn(x, w, groups, **kw)               # (slot [g][1] of a group that straddles no tile boundary is never written)
+        assert torch.equal(again, out) and torch.equal(ops.gn_partials_of(again).buf[..., 0, :], part.buf[..., 0, :])
+        assert torch.equal(ops.groupnorm_apply_nhwc(again, ops.gn_partials_of(again), groups, gamma, beta, 1e-5, True),
+                           ops.groupnorm_apply_nhwc(out, part, groups, gamma, beta, 1e-5, True))
+
+
+@pytest.mark.parametrize("B,L,K,N,groups", [(2, 4096, 320, 320, 32), (2, 1024, 640, 640, 32), (2, 4096, 960, 320, 32), (2, 1024, 1920, 640, 32),
+                                            (4, 256, 128, 64, 4)])
+def test_groupnorm_statistics_from_the_gemm_epilogue(ops, B, L, K, N, groups):
+    """dsc_linear_gn_f16: the 1x1 convolutions (proj_out, conv_shortcut) as token-major GEMMs that also emit the GroupNorm partial
+    sums of their output - same bytes as dsc_linear_f16, one-launch GroupNorm equal to the two-launch one up to summation order"""
+    g = torch.Generator().manual_seed(B + L + K + N)
+    x = torch.randn(B, L, K, generator=g).half().cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.2).half().cuda()
+    r = torch.randn(B, L, N, generator=g).half().cuda()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).half().cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).half().cuda()
+    got = ops.linear_gn(x, w, b, r, L, groups)
+    assert got is not None
+    y, part = got
+    assert torch.equal(y, ops.linear(x, w, b, residual=r, prefer_kernel=True))
+    side = int(round(L ** 0.5))
+    img = y.reshape(B, side, side, N).permute(0, 3, 1, 2)                          # channels_last view of the token tensor
+    for act in (True, False):
+        one = ops.groupnorm_apply_nhwc(img, part, groups, gamma, beta, 1e-6, act)
+        two = ops.groupnorm_silu_nhwc(img, groups, gamma, beta, 1e-6, act)
+        gref = F.group_norm(img.float(), groups, gamma.float(), beta.float(), 1e-6)
+        gref = F.silu(gref) if act else gref
+        assert (one.float() - gref).abs().max().item() < 6e-3 and (one.float() - two.float()).abs().max().item() < 4e-3
+    y2, part2 = ops.linear_gn(x, w, b, r, L, groups)
+    assert torch.equal(y2, y) and torch.equal(part2.buf[..., 0, :], part.buf[..., 0, :])
+    assert torch.equal(ops.groupnorm_apply_nhwc(img, part2, groups, gamma, beta, 1e-6, True), ops.groupnorm_apply_nhwc(img, part, groups, gamma, beta, 1e-6, True))
