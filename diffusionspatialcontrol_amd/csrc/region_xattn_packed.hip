@@ -148,19 +148,31 @@ __device__ __forceinline__ void scores_img(const XattnParams& p, const half_t* i
 }
 
 // ---------------------------------------------------------------------------------------------- statistics
+// K fragments: straight into registers while they fit beside two waves per SIMD (NK <= 5: d <= 80, 9-15 fragments); the wide
+// heads (d = 160: 30 fragments = 120 registers, and their launches have few workgroups: four waves each pulling 30 KiB through
+// L2 took 10.1 us against 6.6) stage the image once per workgroup in LDS
 template <int NK, bool REF16>
 __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 waves per SIMD: score accumulators stay in VGPRs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using P = PCfg<NK>;
+    constexpr bool KREG = NK <= 5;
     const XattnParams& p = pp.x;
-    double* red = reinterpret_cast<double*>(smem);
+    half_t* img = reinterpret_cast<half_t*>(smem);
+    double* red = reinterpret_cast<double*>(smem + (KREG ? 0 : P::KFR * 1024));
     int b, h, chunk;
     block_to_work(p, b, h, chunk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
-    h8_t qf[NK], kf[3 * NK];
+    h8_t qf[NK], kf[KREG ? 3 * NK : 1];
     int l0 = (chunk * kWaves * p.tiles_per_wave + wave) * 32;
     load_q_frags<NK>(p, qf, b, h, min(l0 + r, p.L - 1), hh);
-    load_k_frags<NK>(pp.img + (long long)(b * p.H + h) * P::IMG, kf, lane);
+    if constexpr (KREG) {
+        load_k_frags<NK>(pp.img + (long long)(b * p.H + h) * P::IMG, kf, lane);
+    } else {
+        ImgCopy<P::KFR> imgc;
+        imgc.load(pp.img + (long long)(b * p.H + h) * P::IMG);
+        imgc.store(img);
+        __syncthreads();
+    }
     double d1 = 0.0, d2 = 0.0;
     for (int t = 0; t < p.tiles_per_wave; ++t) {
         l0 = (chunk * kWaves * p.tiles_per_wave + t * kWaves + wave) * 32;
@@ -168,7 +180,8 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
         if (t > 0) load_q_frags<NK>(p, qf, b, h, min(l0 + r, p.L - 1), hh);
         const bool row_ok = l0 + r < p.L;
         f16x_t acc[3];
-        scores_reg<NK, REF16>(kf, qf, acc, p.scale);
+        if constexpr (KREG) scores_reg<NK, REF16>(kf, qf, acc, p.scale);
+        else scores_img<NK, REF16>(p, img, qf, acc, lane, p.scale);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int m = 0; m < 3; ++m)
@@ -606,7 +619,7 @@ int launch_packed(const XpParams& pp, bool need_stats, hipStream_t st) {
         attr_set = true;
     }
     if (need_stats)
-        DSC_LAUNCH((xp_stats<NK, REF16>), grid, block, (size_t)kRedBytes, st, pp);
+        DSC_LAUNCH((xp_stats<NK, REF16>), grid, block, (size_t)(NK <= 5 ? 0 : P::KFR * 1024) + kRedBytes, st, pp);
     const size_t lds = (size_t)P::IMG * 2 + (size_t)kNUMax * kBP * 4 + kRedBytes;
     if constexpr (!REF16 && (NK == 3 || NK == 10)) {           // the diagnostic instantiation (tools/stamps_xattn.py's two shapes)
         if (pp.x.flags & 32u) {

@@ -15,7 +15,7 @@ out = torch.empty(Bc, L, H, d, dtype=torch.half, device=dev)
 q4, k4, v4 = q.view(Bc, L, H, d), k.view(Bc, S, H, d), v.view(Bc, S, H, d)
 packed = ops.xattn_kv_pack(k4, v4)
 ids, rows = ops.compress_region_table(w, pad_rows=True)
-comp = (ids.to(dev), rows.to(dev))
+comp = (ids.to(dev), ops.pad_region_rows(rows).to(dev))        # the pipeline's form: rows in the kernel's own table shape
 # evict L2 / Infinity Cache between launches with a 512 MiB write so the counters see HBM traffic, not cache hits
 scratch = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 for i in range(12):
