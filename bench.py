@@ -165,6 +165,7 @@ def roofline_region_xattn(dev, n_img):
     q4, k4, v4 = q.view(Bc, L, H, d), k.view(Bc, S, H, d), v.view(Bc, S, H, d)
     packed = ops.xattn_kv_pack(k4, v4)
     ids, rows = ops.compress_region_table(w, pad_rows=True)
+    rows = ops.pad_region_rows(rows)                                    # the form the pipeline uploads (model_k_diffusion._compress_tables)
     comp = (ids.to(dev), rows.to(dev))
     call = lambda **kw: ops.region_xattn_packed(q4, packed, S, comp, sig, n_std_groups=n_img, out=out,  # noqa: E731
                                                 ref_fp16_rounding=False, **kw)
