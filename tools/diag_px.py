@@ -22,7 +22,10 @@ if len(sys.argv) > 1:
 else:
     import torch
     outs = {}
-    for name, lib in (("new", ""), ("old", os.path.join(root, "tools", "_ab", "libdsc_old.so"))):
+    old_lib = os.environ.get("DSC_OLD_LIB", os.path.join(root, "tools", "_ab", "libdsc_old.so"))     # another build of the same ABI
+    if not os.path.exists(old_lib):
+        raise SystemExit(f"{old_lib} not found: build another commit's library there (python -m diffusionspatialcontrol_amd.build in a worktree) or set DSC_OLD_LIB")
+    for name, lib in (("new", ""), ("old", old_lib)):
         env = dict(os.environ)
         if lib:
             env["DSC_LIB_PATH"] = lib
