@@ -355,7 +355,8 @@ class _RegionProcessor:
             if not is_self and key.shape[0] != query.shape[0] and key.shape[0] % query.shape[0] == 0:
                 # shared CFG prefix (UNet2DConditionModel.forward): up to the first cross-attention the unconditional and
                 # the conditional rows of the batch are the same numbers and were computed once - from here on they differ
-                query = query.repeat(key.shape[0] // query.shape[0], 1, 1)
+                # (one image: a stride-0 batch dimension - the kernels take the query's strides - instead of a 5 MB copy launch)
+                query = query.expand(key.shape[0], -1, -1) if query.shape[0] == 1 else query.repeat(key.shape[0] // query.shape[0], 1, 1)
             B, L, C = query.shape
             d = C // H
             S = key.shape[1]
