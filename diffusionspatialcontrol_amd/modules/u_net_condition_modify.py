@@ -300,9 +300,7 @@ GN_FUSE_MIN_ROWS = 1024
 
 def _with_gn(img, part):
     """attach a producer's GroupNorm partial sums to the tensor OBJECT handed on (GroupNormAct.forward looks for them)"""
-    if part is not None:
-        img._dsc_gn = part
-    return img
+    return ops.attach_gn_partials(img, part)
 
 
 class Conv1x1(nn.Conv2d):

@@ -330,15 +330,28 @@ USE_GN_FUSE = os.environ.get("DSC_GN_FUSE", "1") != "0"   # GroupNorm statistics
 class GnPartials:
     """the GroupNorm partial sums a producer emitted for the tensor it wrote (dsc_conv3x3_gn_nhwc_f16 / dsc_linear_gn_f16):
     buffer fp32 [B, rows, groups, 2, 2], for a tensor of C channels normalised in `groups` groups"""
-    __slots__ = ("buf", "rows", "groups", "C", "B", "hw")
+    __slots__ = ("buf", "rows", "groups", "C", "B", "hw", "version")
 
     def __init__(self, buf, rows, groups, C, B, hw):
         self.buf, self.rows, self.groups, self.C, self.B, self.hw = buf, rows, groups, C, B, hw
+        self.version = None                   # torch's in-place version counter of the tensor when the sums were attached
+
+
+def attach_gn_partials(t, part):
+    """hand a producer's partial sums on with the tensor OBJECT `t` (a view of the producer's output is fine: same bytes)"""
+    if part is not None:
+        part.version = t._version
+        t._dsc_gn = part
+    return t
 
 
 def gn_partials_of(t):
-    """the GnPartials a producer attached to the tensor OBJECT it returned (views and copies carry none), or None"""
-    return getattr(t, "_dsc_gn", None) if USE_GN_FUSE else None
+    """the GnPartials a producer attached to the tensor OBJECT it returned (views and copies carry none), or None - also None once
+    the tensor has been written in place since (torch's version counter): the sums would describe other bytes"""
+    part = getattr(t, "_dsc_gn", None) if USE_GN_FUSE else None
+    if part is not None and part.version != t._version:
+        return None
+    return part
 
 
 def groupnorm_apply_nhwc(x, part, groups, weight, bias, eps, act):
@@ -397,8 +410,7 @@ def conv3x3_gn(x, weight, groups, bias=None, add=None, residual=None, upsample=F
     rc = lib.dsc_conv3x3_gn_nhwc_f16(_p(x), _p(weight), _p(bias), _p(add), add_ld, _p(residual), _p(out), B, H, W, Cin, Cout, Cin,
                                      ldr, Cout, 1 if upsample else 0, _p(part), groups, 0, _stream_ptr(x))
     _lib.check(rc, "dsc_conv3x3_gn_nhwc_f16")
-    out._dsc_gn = GnPartials(part, rows, groups, Cout, B, H * W)
-    return out
+    return attach_gn_partials(out, GnPartials(part, rows, groups, Cout, B, H * W))
 
 
 def linear_gn(x, weight, bias, residual, rows_per_image, groups):

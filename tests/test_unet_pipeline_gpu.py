@@ -1773,3 +1773,18 @@ def test_groupnorm_statistics_from_the_gemm_epilogue(ops, B, L, K, N, groups):
     y2, part2 = ops.linear_gn(x, w, b, r, L, groups)
     assert torch.equal(y2, y) and torch.equal(part2.buf[..., 0, :], part.buf[..., 0, :])
     assert torch.equal(ops.groupnorm_apply_nhwc(img, part2, groups, gamma, beta, 1e-6, True), ops.groupnorm_apply_nhwc(img, part, groups, gamma, beta, 1e-6, True))
+
+
+def test_groupnorm_partials_are_dropped_after_an_in_place_write(ops):
+    """the partial sums ride on the tensor OBJECT the producer returned; a view made later or an in-place write since (torch's
+    version counter) must not find them - the GroupNorm then computes its own statistics"""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 32, 32, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).half().cuda().contiguous(memory_format=torch.channels_last)
+    if ops.conv3x3_gn_rows(x, w, 8) == 0:
+        pytest.skip("shape not covered")
+    out = ops.conv3x3_gn(x, w, 8)
+    assert ops.gn_partials_of(out) is not None
+    assert ops.gn_partials_of(out[:]) is None and ops.gn_partials_of(out.clone()) is None
+    out.mul_(2.0)
+    assert ops.gn_partials_of(out) is None
