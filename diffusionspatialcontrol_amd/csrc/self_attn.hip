@@ -49,6 +49,7 @@ struct SaParams {
     long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
     unsigned k_bytes, v_bytes;   // extent of one (b, h) slice of K / V: ((S - 1) * row stride + d) * 2
     unsigned long long* stamps;
+    int stamp_wave;
 };
 
 // D8 = 0: generic image - K rows of 2 NK + 1 chunks (2 NK operand chunks, zero beyond the head dim, + 1 chunk that makes the
@@ -90,7 +91,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(uintptr_t)lds_byte, 16, voff, soff, 0, 0);
 }
 
-unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cycle sums of workgroup 0 / wave 0
+unsigned long long* g_sa_stamps = nullptr;
+int g_sa_stamp_wave = 0;        // diagnostic: per-segment cycle sums of workgroup 0 / wave 0
 
 #define SA_STAMP(slot)                                                                          \
     if (dbg) {                                                                                  \
@@ -113,10 +115,11 @@ unsigned long long* g_sa_stamps = nullptr;        // diagnostic: per-segment cyc
 // same time - both in their MFMA chains, then both in their exponentials.  Waves 4-7 therefore run P.V one tile late (its
 // V^T fragments and probabilities stay in registers across the barrier), so that while waves 0-3 are in the softmax their SIMD
 // partners are in QK^T, and while the partners are in the softmax waves 0-3 are in P.V.
-template <int NK, int WAVES, int MINW, int D8, int NLOAD, bool STAGGER>
+template <int NK, int WAVES, int MINW, int D8, int NLOAD, int STAGGER>
 __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaParams p) {
     constexpr bool LOADER = NLOAD > 0;
     static_assert(!STAGGER || (LOADER && WAVES == 8 && NK <= 5), "the stagger is for 8 computing waves with loader waves");
+    static_assert(STAGGER >= 0 && STAGGER <= 2, "0: none, 1: waves 4-7 run P.V one tile late, 2: and waves 0-3 the softmax");
     using C = SaCfg<NK, D8>;
     constexpr int DM = C::DM, KP = C::KP, VP = C::VP, KC = C::KC, VC = C::VC;
     constexpr bool ONES = C::ONES;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     // tile's common immediate (32 (DM-1) halves) lands on column 0
     const unsigned ones_lane = ones0 + (unsigned)((4 * hh + ((lane & 15) >> 2)) * VP + 4 * (lane & 3)) * 2u - 64u * (DM - 1);
 
-    const bool dbg = p.stamps != nullptr && blockIdx.x == 0 && wave == 0;
+    const bool dbg = p.stamps != nullptr && blockIdx.x == 0 && wave == p.stamp_wave;
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -278,74 +281,10 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) o[dm] = mfma_32x32x16(vf[HOIST ? dm : 0][HOIST ? tt : 0], pf[tt], o[dm]);
     };
-    int buf = NBUF - 1;
-    for (int t = 0; t < ntiles; ++t) {
-        buf = buf + 1 == NBUF ? 0 : buf + 1;                 // t % NBUF
-        const int nbuf1 = buf + 1 == NBUF ? 0 : buf + 1;     // (t + 1) % NBUF: where a non-loader kernel stages the next tile
-        // tile t: this wave's pieces have landed (the only DMAs outstanding), then everyone's - and every wave is done
-        // reading buffer buf ^ 1 (tile t-1), so tile t+1 may go there
-        if (LOADER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the ones region's stores, first tile)
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // The compiler puts an `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows an LDS-DMA it has
-        // seen (it cannot tell the transposed read from the DMA's destination).  HOIST kernels therefore issue ALL LDS reads
-        // of tile t first and the DMA of tile t+1 behind them; the others issue the DMA here and pay part of its latency
-        // at their first transposed read.
-        if (!LOADER && !HOIST && t + 1 < ntiles) stage(t + 1, nbuf1);
-        SA_STAMP(0)
-        const unsigned kb = lds0 + buf * C::TILE_BYTES + k_lane;
-        const unsigned vb = lds0 + buf * C::TILE_BYTES + C::K_BYTES + v_lane;
-        const unsigned vb_last = (ONES && g == 1) ? ones_lane : vb;
-
-        auto k_frag = [&](int m, int ks) { return lds_read_h8(kb + (32 * m * KP + 16 * ks) * 2); };
-        auto v_frag = [&](int dm, int tt) {
-            const unsigned a = ((ONES && dm == DM - 1) ? vb_last : vb) + (16 * tt * VP + 32 * dm) * 2;
-            const h4_t lo = lds_read_tr(a);
-            const h4_t hi = lds_read_tr(a + 8 * VP * 2);
-            return h8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        };
-        if (STAGGER && late && t > 0) {                      // the previous tile's P.V, beside the partner wave's QK^T
-            pv_hoisted();
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        h8_t kf[HOIST ? 2 : 1][HOIST ? NK : 1];
-        if constexpr (HOIST) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int ks = 0; ks < NK; ++ks) kf[m][ks] = k_frag(m, ks);
-            if constexpr (!V_LATE) {
-#pragma unroll
-                for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        // ---- S'^T = K . Q'^T - m  (2 row tiles of 32 keys): the chain starts from negm
-        f16x_t s[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-#pragma unroll
-            for (int ks = 0; ks < NK; ++ks) {
-                const h8_t kfr = HOIST ? kf[HOIST ? m : 0][HOIST ? ks : 0] : k_frag(m, ks);
-                s[m] = mfma_32x32x16(kfr, qf[ks], ks == 0 ? negm : s[m]);
-            }
-        }
-        if constexpr (V_LATE) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (dbg) asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
-        SA_STAMP(1)
-
-        // ---- softmax, base 2.  Element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this lane's query row.
+    // ---- softmax, base 2, of the tile whose S'^T sits in s[]: probabilities into pf[], the running max / sums updated
+    f16x_t s[2];
+    auto softmax_tile = [&](int t, int nbuf1) {
+        // Element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this lane's query row.
         const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
         if (kv_left < kKV) {                                 // wave-uniform: only the ragged last tile masks
             const int lim = kv_left - 4 * hh;                // (compared with constants: nothing loop-invariant to keep live)
@@ -398,6 +337,134 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
             }
         }
         if (!ONES) l_run += psum;
+    };
+    // STAGGER == 2: every wave runs the same sequence QK^T(t), softmax(t), P.V(t), QK^T(t+1), ... - what differs is where in
+    // it the tile barrier falls.  Waves 0-3 meet it between QK^T(t) and softmax(t), waves 4-7 between softmax(t) and P.V(t):
+    // within a period the first group runs [softmax(t-1) | P.V(t-1), QK^T(t)] = [VALU | 14 MFMAs] while its SIMD partners run
+    // [P.V(t-1), QK^T(t) | softmax(t)] = [14 MFMAs | VALU].  (STAGGER == 1 leaves waves 0-3 in the plain order, so their
+    // QK^T runs beside the partners' P.V + QK^T: matrix beside matrix on one SIMD.)  Scores and V^T fragments cross the barrier
+    // in registers; both groups read K(t) and V(t) from LDS in period t, as the loader's ring of three assumes.
+    const bool rotated = STAGGER == 2 && !late;              // wave-uniform
+    // (static s_setprio 1 for either group: no gain on the rotated kernel, 69 -> 77 us on STAGGER == 1 with waves 4-7 raised)
+    if constexpr (STAGGER == 2) {
+        if (rotated) {
+            int rb = NBUF - 1;
+            for (int t = 0; t < ntiles; ++t) {
+                rb = rb + 1 == NBUF ? 0 : rb + 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned kb = lds0 + rb * C::TILE_BYTES + k_lane;
+                const unsigned vb = lds0 + rb * C::TILE_BYTES + C::K_BYTES + v_lane;
+                const unsigned vb_last = (ONES && g == 1) ? ones_lane : vb;
+                SA_STAMP(0)
+                if (t > 0) {
+                    softmax_tile(t - 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (dbg) asm volatile("" :: "v"(pf[0][0]), "v"(pf[3][7]));
+                SA_STAMP(2)
+                h8_t kf[2][NK];                              // K(t)'s fragments arrive under P.V(t-1)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ks = 0; ks < NK; ++ks) kf[m][ks] = lds_read_h8(kb + (32 * m * KP + 16 * ks) * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t > 0) {
+                    pv_hoisted();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (dbg) asm volatile("" :: "v"(o[0][0]), "v"(o[DM - 1][15]));
+                SA_STAMP(3)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int ks = 0; ks < NK; ++ks) s[m] = mfma_32x32x16(kf[m][ks], qf[ks], ks == 0 ? negm : s[m]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (dbg) asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
+                SA_STAMP(1)
+#pragma unroll
+                for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+                        const unsigned a = ((ONES && dm == DM - 1) ? vb_last : vb) + (16 * tt * VP + 32 * dm) * 2;
+                        const h4_t lo = lds_read_tr(a);
+                        const h4_t hi = lds_read_tr(a + 8 * VP * 2);
+                        vf[HOIST ? dm : 0][HOIST ? tt : 0] = h8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            softmax_tile(ntiles - 1, 0);
+            pv_hoisted();
+        }
+    }
+    int buf = NBUF - 1;
+    for (int t = 0; t < (rotated ? 0 : ntiles); ++t) {
+        buf = buf + 1 == NBUF ? 0 : buf + 1;                 // t % NBUF
+        const int nbuf1 = buf + 1 == NBUF ? 0 : buf + 1;     // (t + 1) % NBUF: where a non-loader kernel stages the next tile
+        // tile t: this wave's pieces have landed (the only DMAs outstanding), then everyone's - and every wave is done
+        // reading buffer buf ^ 1 (tile t-1), so tile t+1 may go there
+        if (LOADER) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the ones region's stores, first tile)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // The compiler puts an `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 that follows an LDS-DMA it has
+        // seen (it cannot tell the transposed read from the DMA's destination).  HOIST kernels therefore issue ALL LDS reads
+        // of tile t first and the DMA of tile t+1 behind them; the others issue the DMA here and pay part of its latency
+        // at their first transposed read.
+        if (!LOADER && !HOIST && t + 1 < ntiles) stage(t + 1, nbuf1);
+        SA_STAMP(0)
+        const unsigned kb = lds0 + buf * C::TILE_BYTES + k_lane;
+        const unsigned vb = lds0 + buf * C::TILE_BYTES + C::K_BYTES + v_lane;
+        const unsigned vb_last = (ONES && g == 1) ? ones_lane : vb;
+
+        auto k_frag = [&](int m, int ks) { return lds_read_h8(kb + (32 * m * KP + 16 * ks) * 2); };
+        auto v_frag = [&](int dm, int tt) {
+            const unsigned a = ((ONES && dm == DM - 1) ? vb_last : vb) + (16 * tt * VP + 32 * dm) * 2;
+            const h4_t lo = lds_read_tr(a);
+            const h4_t hi = lds_read_tr(a + 8 * VP * 2);
+            return h8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        if (STAGGER && late && t > 0) {                      // the previous tile's P.V, beside the partner wave's QK^T
+            pv_hoisted();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        h8_t kf[HOIST ? 2 : 1][HOIST ? NK : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) kf[m][ks] = k_frag(m, ks);
+            if constexpr (!V_LATE) {
+#pragma unroll
+                for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- S'^T = K . Q'^T - m  (2 row tiles of 32 keys): the chain starts from negm
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int ks = 0; ks < NK; ++ks) {
+                const h8_t kfr = HOIST ? kf[HOIST ? m : 0][HOIST ? ks : 0] : k_frag(m, ks);
+                s[m] = mfma_32x32x16(kfr, qf[ks], ks == 0 ? negm : s[m]);
+            }
+        }
+        if constexpr (V_LATE) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dm = 0; dm < DM; ++dm)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) vf[dm][tt] = v_frag(dm, tt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (dbg) asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
+        SA_STAMP(1)
+
+        softmax_tile(t, nbuf1);
         SA_STAMP(2)
 
         // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels)
@@ -449,7 +516,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     }
 }
 
-template <int NK, int WAVES, int MINW, int D8 = 0, int NLOAD = 0, bool STAGGER = false>
+template <int NK, int WAVES, int MINW, int D8 = 0, int NLOAD = 0, int STAGGER = 0>
 int launch(const SaParams& p0, hipStream_t st) {
     SaParams p = p0;
     p.nqb = (p.L + 32 * WAVES - 1) / (32 * WAVES);
@@ -479,6 +546,7 @@ int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant
 //   4 / 5  4 / 8 computing waves + 1 loader wave        6 / 7  4 / 8 computing waves + 2 loader waves
 //   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13); 11 / 12  as 1 / 2 with it
 //   13 / 14  8 computing waves + 1 / 2 loader waves, waves 4-7 staggered by one P.V (compact image at d = 40)
+//   17 / 18  as 13 / 14, and waves 0-3 staggered by one softmax + P.V (STAGGER == 2: [VALU | MFMA] beside [MFMA | VALU])
 //   15 / 16  2 / 4 computing waves + 4 loader waves (any head dim)
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
@@ -506,13 +574,18 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         if (v == 11 && compact) return launch<3, 4, 2, 5, 0>(p, st);
         if (v == 12 && compact) return launch<3, 8, 2, 5, 0>(p, st);
         constexpr int NS = NK <= 3 ? NK : 3;                  // (the staggered kernel of NK = 4 spills at 168 registers: not built)
-        if (v == 13) return compact ? launch<3, 8, 2, 5, 1, true>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, true>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
-        if (v == 14) return compact ? launch<3, 8, 2, 5, 2, true>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, true>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
+        if (v == 13) return compact ? launch<3, 8, 2, 5, 1, 1>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 1>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
+        if (v == 14) return compact ? launch<3, 8, 2, 5, 2, 1>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 1>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
         // measured (tools/mb_sa.py, head-major K / V): at batch 1 (+CFG) the SD1.5 64x64 level offers 256 workgroups of 256
         // query rows - one per CU, 8 computing waves + a loader wave: 64 us against 70 for two 4-wave workgroups per CU
         // that issue their own DMA; at 8 images the 4-wave workgroups win (480 vs 505 us)
         // (staggered: 64.0 us against 66.6 for the same kernel with all eight waves in phase)
-        if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return compact ? launch<3, 8, 2, 5, 1, true>(p, st) : launch<3, 8, 2, 0, 2, true>(p, st);
+        if (v == 17) return compact ? launch<3, 8, 2, 5, 1, 2>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 2>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
+        if (v == 18) return compact ? launch<3, 8, 2, 5, 2, 2>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 2>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
+        // (round 3, rotated stagger: 60.3 us against 62.3 for STAGGER == 1 at batch 1 + CFG, 472 against 479 for the 4-wave
+        // workgroups at 8 images - the same bits as every other tiling)
+        if (v == 0 && compact && wg8 >= 256) return launch<3, 8, 2, 5, 1, 2>(p, st);
+        if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return launch<3, 8, 2, 0, 2, 1>(p, st);
         // one image's 8 heads (the shared CFG prefix runs the first self-attention once per image): 256 workgroups of 128 query
         // rows, one per CU - four computing waves + two loader waves 43.4 us against 51.8 for the four waves issuing their own DMA
         if (v == 0 && compact && wg4 > 128 && wg4 <= 256) return launch<3, 4, 3, 5, 2>(p, st);
@@ -540,6 +613,7 @@ bool strides_ok(const int64_t s[3]) { return s[0] % 8 == 0 && s[1] % 8 == 0 && s
 }  // namespace
 
 extern "C" void dsc_debug_set_self_attn_variant(int v) { g_sa_variant = v; }
+extern "C" void dsc_debug_set_self_attn_stamp_wave(int w) { g_sa_stamp_wave = w; }
 extern "C" void dsc_debug_set_self_attn_stamps(void* device_buffer_64B) { g_sa_stamps = static_cast<unsigned long long*>(device_buffer_64B); }
 
 extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, void* out, int Bc, int H, int L, int S,
@@ -569,7 +643,7 @@ extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, vo
     p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
     p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
     p.k_bytes = (unsigned)kext; p.v_bytes = (unsigned)vext;
-    p.stamps = g_sa_stamps;
+    p.stamps = g_sa_stamps; p.stamp_wave = g_sa_stamp_wave;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d <= 16) return launch_nk<1>(p, st);
     if (d <= 32) return launch_nk<2>(p, st);
