@@ -584,7 +584,8 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         if (v == 18) return compact ? launch<3, 8, 2, 5, 2, 2>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 2>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
         // (round 3, rotated stagger: 60.3 us against 62.3 for STAGGER == 1 at batch 1 + CFG, 472 against 479 for the 4-wave
         // workgroups at 8 images - the same bits as every other tiling)
-        if (v == 0 && compact && wg8 >= 256) return launch<3, 8, 2, 5, 1, 2>(p, st);
+        // (in the step, 64x64 level: 73.6 us STAGGER == 1 -> 69.1 rotated, one loader wave -> 67.2 with two)
+        if (v == 0 && compact && wg8 >= 256) return launch<3, 8, 2, 5, 2, 2>(p, st);
         if (v == 0 && NK == 3 && wg8 >= 256 && wg8 < 512) return launch<3, 8, 2, 0, 2, 1>(p, st);
         // one image's 8 heads (the shared CFG prefix runs the first self-attention once per image): 256 workgroups of 128 query
         // rows, one per CU - four computing waves + two loader waves 43.4 us against 51.8 for the four waves issuing their own DMA
