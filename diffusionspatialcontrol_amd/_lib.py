@@ -37,6 +37,7 @@ _SIGNATURES = {
     "dsc_debug_set_stamp_buffer": (None, [_vp]),
     "dsc_debug_set_self_attn_variant": (None, [ctypes.c_int]),
     "dsc_debug_set_self_attn_stamps": (None, [_vp]),
+    "dsc_debug_set_gemm_stamps": (None, [_vp]),
     "dsc_debug_set_self_attn_stamp_wave": (None, [ctypes.c_int]),
     "dsc_region_xattn_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
     "dsc_region_xattn_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp] + [ctypes.c_int] * 7 + [_i64p] * 4 +

@@ -66,6 +66,7 @@ struct GemmParams {
     // dsc_linear_gn_f16: GroupNorm partial sums of the stored tensor (gn_partials.h): rows are pixels, gn_L of them per image
     // (gn_L % BM == 0: a row tile lies in one image), 64-column tiles only
     float* gn_part; int gn_cpg, gn_G, gn_L;
+    long long* stamps;           // diagnostics (dsc_debug_set_gemm_stamps): 8 x int64 per workgroup, NULL in normal calls
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         bid = (bid & 7) * per + (bid >> 3);
         if (bid >= p.total) return;                          // grid padded to a multiple of 8 (before any barrier)
     }
+    long long st0 = 0, st1 = 0, st2 = 0, sc0 = 0, sc1 = 0, sc2 = 0;
+    if (p.stamps) { st0 = __builtin_amdgcn_s_memrealtime(); sc0 = __builtin_amdgcn_s_memtime(); }
     int kbeg = 0;                                            // first K tile of this workgroup (split-K)
     if (p.splits > 1) {
         const int sp = bid / p.tiles;
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         else asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // raw: publishes tile kt, proves tile kt-1's reads are done
         asm volatile("" ::: "memory");
+        if (p.stamps && kt == 0) { st1 = __builtin_amdgcn_s_memrealtime(); sc1 = __builtin_amdgcn_s_memtime(); }
         if (!LOADER && kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
         const half_t* a = lds + buf * kStage;
         const half_t* b = a + kAHalves;
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
         }
     }
     __syncthreads();                                         // all MFMA operand reads done: LDS becomes the epilogue stage
+    if (p.stamps) { st2 = __builtin_amdgcn_s_memrealtime(); sc2 = __builtin_amdgcn_s_memtime(); }
 
     // ---- epilogue stage: stage[m][n] fp32; acc[mt] element i <-> n = wn*32 + (i&3) + 8(i>>2) + 4hh, m = wm*64 + mt*32 + r
     float* stage = reinterpret_cast<float*>(smem);
@@ -390,6 +395,15 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             }
         }
     }
+    if (p.stamps && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the output stores have left
+        long long* o = p.stamps + (long long)blockIdx.x * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memrealtime();
+        o[4] = sc1 - sc0; o[5] = sc2 - sc1; o[6] = __builtin_amdgcn_s_memtime() - sc2; o[7] = ((long long)xcc << 32) | hwid;
+    }
 }
 
 // out = sum over the splits (in split order) + bias + residual, one fp16 rounding (the second launch of dsc_linear_splitk_f16)
@@ -418,6 +432,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* ws, const
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+long long* g_gemm_stamps = nullptr;
 int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 = default, 2 / 3 = forced ring depth
 int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
 int g_gemm_loaders = 0;          // ... (stages / 10000 % 10): 0 = default (loader waves for the 64-row tiles), 4 = for every tile, 9 = never
@@ -426,6 +441,7 @@ int g_gemm_nt = 0;               // ... (stages / 100000): 0 = default (128-colu
 
 }  // namespace
 
+extern "C" void dsc_debug_set_gemm_stamps(void* device_buffer) { g_gemm_stamps = static_cast<long long*>(device_buffer); }
 extern "C" void dsc_debug_set_gemm_stages(int stages) {
     // stages % 10: ring depth (2, 3; else default); stages / 10: tile height (64, 128; else default) - e.g. 640 + 3
     const int bm = (stages / 10) % 1000, st = stages % 10;
@@ -491,6 +507,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     if (!al16(x) || !al16(w) || !al16(out) || (bias && !al16(bias)) || (residual && !al16(residual))) return DSC_ERR_UNSUPPORTED;
     if (M > (1ll << 30)) return DSC_ERR_UNSUPPORTED;
     GemmParams p{};
+    p.stamps = g_gemm_stamps;
     p.x = static_cast<const half_t*>(x); p.w = static_cast<const half_t*>(w);
     p.bias = static_cast<const half_t*>(bias); p.res = static_cast<const half_t*>(residual);
     p.out = static_cast<half_t*>(out);

@@ -48,8 +48,7 @@ struct SaParams {
     float scale_log2e;
     long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
     unsigned k_bytes, v_bytes;   // extent of one (b, h) slice of K / V: ((S - 1) * row stride + d) * 2
-    unsigned long long* stamps;
-    int stamp_wave;
+    unsigned long long* stamps;  // diagnostics; the stamping wave's index rides in the pointer's low three bits (no extra SGPR)
 };
 
 // D8 = 0: generic image - K rows of 2 NK + 1 chunks (2 NK operand chunks, zero beyond the head dim, + 1 chunk that makes the
@@ -101,6 +100,62 @@ int g_sa_stamp_wave = 0;        // diagnostic: per-segment cycle sums of workgro
         __builtin_amdgcn_s_waitcnt(0xC07F);                                                     \
         seg[slot] += t_ - tprev; tprev = t_;                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+
+// The online softmax of the tile whose S'^T sits in s[2] (element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of the lane's
+// query row), as two pieces of TEXT: the tile loop has two shapes (plain and rotated, below) and both paste them.  They were
+// lambdas for one commit: a lambda around this block - even one the DMA lambda `stage_part` is not called from - kept 10-30 more
+// SGPRs live in EVERY instantiation (SGPR spills, a 36-byte scratch frame in 15 kernels; tests/test_cabi.py).
+// HEAD: the ragged last tile's mask, the tile maximum, the (rare) rescale of the running state.  T = tile index.
+#define SA_SOFTMAX_HEAD(T)                                                                                              \
+    {                                                                                                                   \
+        const int t_ = (T);                                                                                             \
+        const int kv_left = p.S - t_ * kKV;                  /* keys valid in this tile (>= 64 except the last) */       \
+        if (kv_left < kKV) {                                 /* wave-uniform: only the ragged last tile masks */         \
+            /* element i of s[m] is key c = 32 m + (i & 3) + 8 (i >> 2) in lanes 0-31 and c + 4 in lanes 32-63: the keep mask  */  \
+            /* is two scalar compares per element - a per-lane bound and a hoisted register of -inf cost every instantiation */  \
+            /* two VGPRs for the whole loop (the rotated kernels spilled at 168)                                             */  \
+            float ninf;                                      /* (materialised HERE: hoisted, it is a register for the whole loop) */ \
+            asm volatile("v_mov_b32 %0, 0xff800000" : "=v"(ninf));                                                      \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                               \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                                        \
+                    const int c = 32 * m + (i & 3) + 8 * (i >> 2);                                                      \
+                    const unsigned long long keep = (c < kv_left ? 0x00000000FFFFFFFFull : 0ull) |                      \
+                                                    (c + 4 < kv_left ? 0xFFFFFFFF00000000ull : 0ull);                   \
+                    asm("v_cndmask_b32_e64 %0, %2, %0, %1" : "+v"(s[m][i]) : "s"(keep), "v"(ninf));                     \
+                }                                                                                                       \
+        }                                                                                                               \
+        float mxa = max3(s[0][0], s[0][1], s[0][2]), mxb = max3(s[1][0], s[1][1], s[1][2]);                             \
+        _Pragma("unroll") for (int i = 3; i < 15; i += 2) {                                                             \
+            mxa = max3(mxa, s[0][i], s[0][i + 1]); mxb = max3(mxb, s[1][i], s[1][i + 1]);                               \
+        }                                                                                                               \
+        float mx = max3(mxa, mxb, s[0][15]);                                                                            \
+        mx = max3(mx, s[1][15], s[1][15]);                                                                              \
+        if (t_ == 0 || __any(mx > kTau)) {                   /* wave-uniform and rare after the first tiles */           \
+            /* the row's maximum over all 64 keys (the other half of the keys lives in lane ^ 32) */                    \
+            const float mrow = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                       \
+            const float delta = t_ == 0 ? mrow : fmaxf(mrow, 0.f);         /* the running max only grows */              \
+            const float alpha = t_ == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);                                         \
+            l_run *= alpha;                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) negm[i] -= delta;                                            \
+            _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                               \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) s[m][i] -= delta;                                        \
+            _Pragma("unroll") for (int dm = 0; dm < DM; ++dm)                                                           \
+                _Pragma("unroll") for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;                                       \
+        }                                                                                                               \
+        psum = 0.f;                                                                                                     \
+    }
+// HALF: the exponentials of keys 32 M .. 32 M + 31 -> pf[2 M], pf[2 M + 1] (and, without the ones column, their sum)
+#define SA_SOFTMAX_HALF(M)                                                                                              \
+    {                                                                                                                   \
+        const int m_ = (M);                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; i += 2) {                                                             \
+            const float e0 = __builtin_amdgcn_exp2f(s[m_][i]), e1 = __builtin_amdgcn_exp2f(s[m_][i + 1]);               \
+            if (!ONES) psum += e0 + e1;                                                                                 \
+            const h2_t pk = __builtin_convertvector(f2x_t{e0, e1}, h2_t);          /* v_cvt_pk_f16_f32 */                \
+            pf[2 * m_ + (i >> 3)][i & 7] = pk[0];                                                                       \
+            pf[2 * m_ + (i >> 3)][(i & 7) + 1] = pk[1];                                                                 \
+        }                                                                                                               \
     }
 
 // MINW = minimum waves per SIMD the register allocation must allow (HIP's second launch bound).  With it the compiler
@@ -268,7 +323,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     // tile's common immediate (32 (DM-1) halves) lands on column 0
     const unsigned ones_lane = ones0 + (unsigned)((4 * hh + ((lane & 15) >> 2)) * VP + 4 * (lane & 3)) * 2u - 64u * (DM - 1);
 
-    const bool dbg = p.stamps != nullptr && blockIdx.x == 0 && wave == p.stamp_wave;
+    const bool dbg = p.stamps != nullptr && blockIdx.x == 0 && wave == (int)(reinterpret_cast<uintptr_t>(p.stamps) & 7);
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tprev = dbg ? __builtin_amdgcn_s_memtime() : 0;
 
@@ -283,61 +338,7 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     };
     // ---- softmax, base 2, of the tile whose S'^T sits in s[]: probabilities into pf[], the running max / sums updated
     f16x_t s[2];
-    auto softmax_tile = [&](int t, int nbuf1) {
-        // Element i of s[m] is key 32 m + (i & 3) + 8 (i >> 2) + 4 hh of this lane's query row.
-        const int kv_left = p.S - t * kKV;                   // keys valid in this tile (>= 64 except the last)
-        if (kv_left < kKV) {                                 // wave-uniform: only the ragged last tile masks
-            const int lim = kv_left - 4 * hh;                // (compared with constants: nothing loop-invariant to keep live)
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (32 * m + (i & 3) + 8 * (i >> 2) >= lim) s[m][i] = -INFINITY;
-        }
-        float mxa = max3(s[0][0], s[0][1], s[0][2]), mxb = max3(s[1][0], s[1][1], s[1][2]);
-#pragma unroll
-        for (int i = 3; i < 15; i += 2) { mxa = max3(mxa, s[0][i], s[0][i + 1]); mxb = max3(mxb, s[1][i], s[1][i + 1]); }
-        float mx = max3(mxa, mxb, s[0][15]);
-        mx = max3(mx, s[1][15], s[1][15]);
-        if (t == 0 || __any(mx > kTau)) {                    // wave-uniform and rare after the first tiles
-            // the row's maximum over all 64 keys (the other half of the keys lives in lane ^ 32)
-            const float mrow = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float delta = t == 0 ? mrow : fmaxf(mrow, 0.f);          // the running max only grows
-            const float alpha = t == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) negm[i] -= delta;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) s[m][i] -= delta;
-#pragma unroll
-            for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[dm][i] *= alpha;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            // HOIST kernels: the DMA of tile t+1 is issued HERE, behind every LDS read of tile t (see above) and in the
-            // VALU-only stretch of the tile (an LDS-DMA instruction issued among LDS reads costs 2-3x as much issue time):
-            // the K image before the first half of the exponentials, the V image before the second
-            if (!LOADER && HOIST && t + 1 < ntiles) {
-                __builtin_amdgcn_sched_barrier(0);
-                stage_part(t + 1, nbuf1, m);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const float e0 = __builtin_amdgcn_exp2f(s[m][i]), e1 = __builtin_amdgcn_exp2f(s[m][i + 1]);
-                if (!ONES) psum += e0 + e1;
-                const h2_t pk = __builtin_convertvector(f2x_t{e0, e1}, h2_t);          // v_cvt_pk_f16_f32
-                pf[2 * m + (i >> 3)][i & 7] = pk[0];
-                pf[2 * m + (i >> 3)][(i & 7) + 1] = pk[1];
-            }
-        }
-        if (!ONES) l_run += psum;
-    };
+    float psum = 0.f;
     // STAGGER == 2: every wave runs the same sequence QK^T(t), softmax(t), P.V(t), QK^T(t+1), ... - what differs is where in
     // it the tile barrier falls.  Waves 0-3 meet it between QK^T(t) and softmax(t), waves 4-7 between softmax(t) and P.V(t):
     // within a period the first group runs [softmax(t-1) | P.V(t-1), QK^T(t)] = [VALU | 14 MFMAs] while its SIMD partners run
@@ -359,19 +360,35 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
                 const unsigned vb_last = (ONES && g == 1) ? ones_lane : vb;
                 SA_STAMP(0)
                 if (t > 0) {
-                    softmax_tile(t - 1, 0);
+                    SA_SOFTMAX_HEAD(t - 1)
+                    SA_SOFTMAX_HALF(0)
+                    SA_SOFTMAX_HALF(1)
+                    if (!ONES) l_run += psum;
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (dbg) asm volatile("" :: "v"(pf[0][0]), "v"(pf[3][7]));
                 SA_STAMP(2)
-                h8_t kf[2][NK];                              // K(t)'s fragments arrive under P.V(t-1)
+                // K(t)'s fragments are read in the middle of P.V(t-1): behind its key steps 0 and 1, whose probabilities and V^T
+                // fragments are dead by then (read in front of P.V they made the kernel spill at 168 registers), and with key
+                // steps 2 and 3 - four MFMAs - to arrive under
+                if (t > 0) {
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int dm = 0; dm < DM; ++dm) o[dm] = mfma_32x32x16(vf[HOIST ? dm : 0][HOIST ? tt : 0], pf[tt], o[dm]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                h8_t kf[2][NK];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int ks = 0; ks < NK; ++ks) kf[m][ks] = lds_read_h8(kb + (32 * m * KP + 16 * ks) * 2);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t > 0) {
-                    pv_hoisted();
+#pragma unroll
+                    for (int tt = 2; tt < 4; ++tt)
+#pragma unroll
+                        for (int dm = 0; dm < DM; ++dm) o[dm] = mfma_32x32x16(vf[HOIST ? dm : 0][HOIST ? tt : 0], pf[tt], o[dm]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (dbg) asm volatile("" :: "v"(o[0][0]), "v"(o[DM - 1][15]));
@@ -394,12 +411,22 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            softmax_tile(ntiles - 1, 0);
+            // (the tile index goes through an opaque move: known before the loop, the ragged-tile mask bound `lim` of the last tile
+            // was computed up there and kept - spilled - across the whole loop)
+            int t_last = ntiles - 1;
+            asm volatile("" : "+s"(t_last));
+            SA_SOFTMAX_HEAD(t_last)
+            SA_SOFTMAX_HALF(0)
+            SA_SOFTMAX_HALF(1)
+            if (!ONES) l_run += psum;
             pv_hoisted();
         }
     }
+    // (an `else` of the rotated loop, not a loop of zero trips behind it: what only this path needs - the LDS lane offsets - would
+    // otherwise stay live, i.e. spilled, across the rotated loop)
+    if (!rotated) {
     int buf = NBUF - 1;
-    for (int t = 0; t < (rotated ? 0 : ntiles); ++t) {
+    for (int t = 0; t < ntiles; ++t) {
         buf = buf + 1 == NBUF ? 0 : buf + 1;                 // t % NBUF
         const int nbuf1 = buf + 1 == NBUF ? 0 : buf + 1;     // (t + 1) % NBUF: where a non-loader kernel stages the next tile
         // tile t: this wave's pieces have landed (the only DMAs outstanding), then everyone's - and every wave is done
@@ -464,7 +491,20 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
         if (dbg) asm volatile("" :: "v"(s[0][0]), "v"(s[1][15]));
         SA_STAMP(1)
 
-        softmax_tile(t, nbuf1);
+        SA_SOFTMAX_HEAD(t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            // HOIST kernels: the DMA of tile t+1 is issued HERE, behind every LDS read of tile t (see above) and in the
+            // VALU-only stretch of the tile (an LDS-DMA instruction issued among LDS reads costs 2-3x as much issue time):
+            // the K image before the first half of the exponentials, the V image before the second
+            if (!LOADER && HOIST && t + 1 < ntiles) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_part(t + 1, nbuf1, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            SA_SOFTMAX_HALF(m)
+        }
+        if (!ONES) l_run += psum;
         SA_STAMP(2)
 
         // ---- O^T += V^T . P^T  (4 k-steps of 16 keys, DM row tiles of 32 channels)
@@ -484,8 +524,11 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
         SA_STAMP(3)
     }
     if (STAGGER && late) pv_hoisted();                       // the last tile's P.V of the late waves
-    if (dbg && lane == 0)
-        for (int i = 0; i < 6; ++i) p.stamps[i] = seg[i];
+    }
+    if (dbg && lane == 0) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(p.stamps) & ~uintptr_t(7));
+        for (int i = 0; i < 6; ++i) dst[i] = seg[i];
+    }
 
     // ---- epilogue: O / l, fp16, out[b, q, h, :].  The lane id is re-derived here (v_mbcnt) so that nothing the epilogue
     // addresses with has to stay live - or be spilled - across the tile loop of the 168-register kernels
@@ -546,7 +589,7 @@ int g_sa_variant = 0;            // tuning knob (dsc_debug_set_self_attn_variant
 //   4 / 5  4 / 8 computing waves + 1 loader wave        6 / 7  4 / 8 computing waves + 2 loader waves
 //   8 / 9 / 10  as 6 / 7 / 5 with the compact d = 40 image (10 DMA pieces per tile instead of 13); 11 / 12  as 1 / 2 with it
 //   13 / 14  8 computing waves + 1 / 2 loader waves, waves 4-7 staggered by one P.V (compact image at d = 40)
-//   17 / 18  as 13 / 14, and waves 0-3 staggered by one softmax + P.V (STAGGER == 2: [VALU | MFMA] beside [MFMA | VALU])
+//   17 / 18  as 14, and waves 0-3 staggered by one softmax + P.V (STAGGER == 2: [VALU | MFMA] beside [MFMA | VALU]); d = 40 only
 //   15 / 16  2 / 4 computing waves + 4 loader waves (any head dim)
 template <int NK>
 int launch_nk(const SaParams& p, hipStream_t st) {
@@ -580,8 +623,9 @@ int launch_nk(const SaParams& p, hipStream_t st) {
         // query rows - one per CU, 8 computing waves + a loader wave: 64 us against 70 for two 4-wave workgroups per CU
         // that issue their own DMA; at 8 images the 4-wave workgroups win (480 vs 505 us)
         // (staggered: 64.0 us against 66.6 for the same kernel with all eight waves in phase)
-        if (v == 17) return compact ? launch<3, 8, 2, 5, 1, 2>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 2>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
-        if (v == 18) return compact ? launch<3, 8, 2, 5, 2, 2>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 2>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
+        // (the rotated stagger exists for the compact d = 40 image with two loader waves only: with one loader wave, or with the
+        // generic image, it spills at 168 registers; every other head dim keeps STAGGER == 1 under 17 / 18)
+        if (v == 17 || v == 18) return compact ? launch<3, 8, 2, 5, 2, 2>(p, st) : (NK <= 3 ? launch<NS, 8, 2, 0, 2, 1>(p, st) : launch<NL, 8, 2, 0, 2>(p, st));
         // (round 3, rotated stagger: 60.3 us against 62.3 for STAGGER == 1 at batch 1 + CFG, 472 against 479 for the 4-wave
         // workgroups at 8 images - the same bits as every other tiling)
         // (in the step, 64x64 level: 73.6 us STAGGER == 1 -> 69.1 rotated, one loader wave -> 67.2 with two)
@@ -644,7 +688,7 @@ extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, vo
     p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
     p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
     p.k_bytes = (unsigned)kext; p.v_bytes = (unsigned)vext;
-    p.stamps = g_sa_stamps; p.stamp_wave = g_sa_stamp_wave;
+    p.stamps = g_sa_stamps ? reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(g_sa_stamps) | (uintptr_t)(g_sa_stamp_wave & 7)) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d <= 16) return launch_nk<1>(p, st);
     if (d <= 32) return launch_nk<2>(p, st);

@@ -56,6 +56,7 @@ void dsc_debug_set_stamp_buffer(void* device_buffer_2KiB);
 void dsc_debug_set_self_attn_variant(int variant);
 /* Diagnostic: 6 x u64 per-segment cycle sums of workgroup 0 / wave 0 of the flash self-attention kernel (NULL = off). */
 void dsc_debug_set_self_attn_stamps(void* device_buffer_64B);
+void dsc_debug_set_gemm_stamps(void* device_buffer);   /* 8 x int64 per workgroup of the next gemm_tn_f16 launches (tools/stamps_gemm.py) */
 void dsc_debug_set_self_attn_stamp_wave(int wave);    /* which wave of workgroup 0 writes them (default 0) */
 /* Human-readable text for a status code. */
 const char* dsc_status_string(int status);
