@@ -182,16 +182,25 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
         f16x_t acc[3];
         if constexpr (KREG) scores_reg<NK, REF16>(kf, qf, acc, p.scale);
         else scores_img<NK, REF16>(p, img, qf, acc, lane, p.scale);
+        // keys >= S count as 0 (only the 32-key tile S cuts needs a select: scalar lane masks, xattn_shared.h), and a lane whose
+        // query row is beyond L drops its sums as a whole - same additions in the same order as a select per element
         float s1 = 0.f, s2 = 0.f;
+        const int S_now = dsc_xattn::opaque_s(p.S);
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < 3; ++m) {
+            if (32 * m + 32 <= S_now) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int s = 32 * m + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const float a = (row_ok && s < p.S) ? acc[m][i] : 0.f;
-                s1 += a;
-                s2 += a * a;
+                for (int i = 0; i < 16; ++i) { const float a = acc[m][i]; s1 += a; s2 += a * a; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float a = dsc_xattn::keep_or_zero(acc[m][i], dsc_xattn::key_keep_mask(32 * m + (i & 3) + 8 * (i >> 2), S_now));
+                    s1 += a;
+                    s2 += a * a;
+                }
             }
+        }
+        if (!row_ok) { s1 = 0.f; s2 = 0.f; }
         d1 += (double)s1; d2 += (double)s2;
     }
     d1 = wave_sum_f64(d1);

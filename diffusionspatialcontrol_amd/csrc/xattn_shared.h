@@ -233,6 +233,24 @@ __device__ __forceinline__ float group_std(const XattnParams& p, int g, double* 
 // an fp32 value the compiler must materialise as computed: no contraction into the consumer (emulation mode only)
 __device__ __forceinline__ float pin_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 
+// Key-validity lane masks.  Element (m, i) of a score tile is key c = 32 m + (i & 3) + 8 (i >> 2) in lanes 0-31 and c + 4 in lanes
+// 32-63, so "key < S" is two SCALAR compares per element.  Written as a per-lane compare (`s < S` with s built from hh) each
+// element is a loop-invariant v_cmp whose 64-bit result the compiler computes once per kernel and keeps: 16-48 SGPR pairs,
+// spilled to VGPR lanes and read back two v_readlane at a time (xp_fwd<3>: 58 spilled SGPRs, xp_stats: 35-41).
+// `S_now` must come from opaque_s() inside the tile loop, or the masks are hoisted out of it all the same.
+__device__ __forceinline__ int opaque_s(int S) { asm volatile("" : "+s"(S)); return S; }
+__device__ __forceinline__ unsigned long long key_keep_mask(int c, int S_now) {
+    return (c < S_now ? 0x00000000FFFFFFFFull : 0ull) | (c + 4 < S_now ? 0xFFFFFFFF00000000ull : 0ull);
+}
+__device__ __forceinline__ float keep_or_zero(float a, unsigned long long keep) {
+    asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(a) : "s"(keep));
+    return a;
+}
+__device__ __forceinline__ float keep_or(float a, float other, unsigned long long keep) {
+    asm("v_cndmask_b32_e64 %0, %2, %0, %1" : "+v"(a) : "s"(keep), "v"(other));
+    return a;
+}
+
 // Bias of the 4 consecutive keys 32m + 8g + 4hh + {0..3} of this lane's row.  VEC: the row lives in LDS with a
 // 16-byte-aligned base and zero padding up to key 99 (packed kernel: one ds_read_b128); else scalar, address clamped.
 template <bool VEC>
@@ -310,16 +328,22 @@ __device__ __forceinline__ float softmax_tile_lean(f16x_t (&acc)[3], h8_t (&pf)[
     const float bmul = (mul1 * mul2) * (1.4426950408889634f / scale_log2e);     // sigma * std / scale
     float mx = -INFINITY;
     auto pass1 = [&](int m, auto masked) {
+        float ninf = 0.f;
+        int S_now = S;
+        if (decltype(masked)::value) {                         // (-inf lives in a register for this tile only)
+            asm volatile("v_mov_b32 %0, 0xff800000" : "=v"(ninf));
+            S_now = opaque_s(S);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float bias[4] = {0.f, 0.f, 0.f, 0.f};
             if (brow) bias4<VEC>(brow, 32 * m + 8 * g + 4 * hh, smax, bias);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int i = 4 * g + j, s = 32 * m + 8 * g + 4 * hh + j;
+                const int i = 4 * g + j;
                 float a = acc[m][i];
                 if (brow) a = fmaf(bias[j], bmul, a);
-                if (decltype(masked)::value) a = s < S ? a : -INFINITY;
+                if (decltype(masked)::value) a = keep_or(a, ninf, key_keep_mask(32 * m + 8 * g + j, S_now));
                 acc[m][i] = a;
                 mx = fmaxf(mx, a);
             }
