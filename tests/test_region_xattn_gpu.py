@@ -214,6 +214,27 @@ def test_packed_path_equals_generic_and_oracle(ops, Bc, H, L, S, d, Bw, ng):
     assert torch.equal(out0.transpose(1, 2), gen0)
 
 
+@pytest.mark.parametrize("S", [3, 4, 5, 28, 31, 32, 33, 36, 37, 60, 63, 64, 65, 68, 69, 92, 95, 96])
+def test_key_count_edges_of_the_lane_masks(ops, S):
+    """The key-validity masks of the fp32-score kernels are built from scalar compares (lanes 0-31 hold key c, lanes 32-63 key
+    c + 4 of every element: xattn_shared.h key_keep_mask): key counts on both sides of every 32-key tile edge and of the +4 lane
+    half offset, packed forward and statistics against the fp32 oracle, packed against the generic kernel."""
+    Bc, H, L, d = 2, 2, 100, 40
+    x = attn_inputs(f"edges/{S}", Bc=Bc, H=H, L=L, S=S, d=d, Bw=2)
+    q, k, v, w = (torch.from_numpy(x[n]) for n in ("q", "k", "v", "w"))
+    qd, kd, vd = q.cuda().half(), k.cuda().half(), v.cuda().half()
+    packed = ops.xattn_kv_pack(kd, vd, layout="bhld")
+    ids, rows = ops.compress_region_table(w.cuda())
+    q_blhd = qd.transpose(1, 2)
+    for bias in ((ids, ops.pad_region_rows(rows)), None):
+        lean_p = ops.region_xattn_packed(q_blhd, packed, S, bias, 2.0, ref_fp16_rounding=False)
+        lean_g = ops.region_xattn(qd, kd, vd, w.cuda() if bias else None, 2.0, ref_fp16_rounding=False)
+        assert torch.isfinite(lean_p).all()
+        assert (lean_p.transpose(1, 2).float() - lean_g.float()).abs().max().item() < 1e-3
+        exp32 = ra.region_attention(q, k, v, w if bias else torch.zeros_like(w), 2.0)
+        assert (lean_p.transpose(1, 2).float().cpu() - exp32).abs().max().item() < ATOL32
+
+
 LONG_SHAPES = [(2, 8, 4096, 154, 40, 2, 1), (2, 8, 1024, 231, 80, 2, 1), (2, 8, 256, 154, 160, 2, 1), (2, 8, 64, 231, 160, 2, 1),
                (4, 8, 1024, 154, 40, 4, 2), (2, 10, 512, 308, 64, 2, 1), (2, 2, 70, 97, 8, 1, 1), (2, 4, 100, 384, 16, 2, 1)]
 
