@@ -174,6 +174,24 @@ def test_self_attention_tiling_variants(ops, variant, B, H, L, d):
     assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("S", [1, 3, 4, 5, 59, 60, 61, 63, 64, 65, 67, 68, 69, 124, 127, 128, 129, 132])
+@pytest.mark.parametrize("d,L", [(40, 4096), (64, 96)])
+def test_attention_key_count_edges(ops, S, d, L):
+    """the ragged last key tile of the flash kernel is masked with lane masks built from scalar compares (lanes 0-31 hold key c,
+    lanes 32-63 key c + 4 of every score element): key counts on both sides of the 64-key tile edge and of the lane-half offset,
+    on the rotated-stagger kernel (d = 40, 4096 query rows) and a plain one"""
+    g = torch.Generator().manual_seed(S * 131 + d)
+    B, H = 2, 8
+    q = torch.randn(B, L, H, d, generator=g).half().cuda()
+    k = torch.randn(B, S, H, d, generator=g).half().cuda()
+    v = torch.randn(B, S, H, d, generator=g).half().cuda()
+    k, v = (t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3) for t in (k, v))     # head-major, as the QKV projection writes them
+    out = ops.self_attention(q, k, v)
+    ref = F.scaled_dot_product_attention(q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2)
+    err = (out.float() - ref).abs()
+    assert torch.isfinite(out).all() and err.max().item() < 3e-3, err.max().item()
+
+
 @pytest.mark.parametrize("B,H,L,S,d", [(2, 8, 4096, 257, 40), (2, 8, 256, 257, 160), (1, 8, 1024, 77, 80), (2, 5, 64, 300, 64)])
 def test_attention_keys_differ_from_queries(ops, B, H, L, S, d):
     """dsc_self_attn_fwd with S != L (a ragged last key tile): the IP-Adapter image-token attention of the 257-token variants"""
