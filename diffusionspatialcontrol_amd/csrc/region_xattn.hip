@@ -109,8 +109,8 @@ __global__ __launch_bounds__(kThreads, 2) void xattn_stats(XattnParams p) {   //
     if (threadIdx.x == 0) {
         double a1 = 0.0, a2 = 0.0;
         for (int w = 0; w < kWaves; ++w) { a1 += red[2 * w]; a2 += red[2 * w + 1]; }
-        const int g = b % p.n_groups;
-        const int idx = ((b / p.n_groups) * p.H + h) * p.nchunks + chunk;
+        const int bg = fdiv(b, p.fd_ngroups), g = b - bg * p.n_groups;
+        const int idx = (bg * p.H + h) * p.nchunks + chunk;
         double* dst = p.partials + ((long long)g * p.npart + idx) * 2;
         dst[0] = a1; dst[1] = a2;
     }
@@ -144,14 +144,14 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xattn_fwd(XattnPa
     const bool need_std = has_bias && !(p.flags & DSC_FLAG_BIAS_IS_FINAL);
     const int wt_stride = (32 * p.S + 3) & ~3;
     float* Wt = Wt_all + wave * wt_stride;
-    const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;   // repeat_interleave, :96-99
+    const int bw = has_bias ? fdiv(b * p.H + h, p.fd_rep) : 0;   // repeat_interleave, :96-99
     const int mt = (p.S + 31) >> 5, nt = (p.S + 15) >> 4;
 
     // ---- prologue: every global load of the workgroup is issued before anything waits
     h8_t kr[C::CH], vr[C::CH];
     kv_load<NK, true>(p, b, h, kr, vr);
     double pa1 = 0.0, pa2 = 0.0;
-    if (need_std) group_partials(p, b % p.n_groups, pa1, pa2);
+    if (need_std) group_partials(p, b - fdiv(b, p.fd_ngroups) * p.n_groups, pa1, pa2);
     float sig = 1.f;
     if (need_std) sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
 

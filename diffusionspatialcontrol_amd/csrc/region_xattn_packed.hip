@@ -210,8 +210,8 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats(XpParams pp) {   // 2 wa
     if (threadIdx.x == 0) {
         double a1 = 0.0, a2 = 0.0;
         for (int w = 0; w < kWaves; ++w) { a1 += red[2 * w]; a2 += red[2 * w + 1]; }
-        const int g = b % p.n_groups;
-        const int idx = ((b / p.n_groups) * p.H + h) * p.nchunks + chunk;
+        const int bg = fdiv(b, p.fd_ngroups), g = b - bg * p.n_groups;
+        const int idx = (bg * p.H + h) * p.nchunks + chunk;
         double* dst = p.partials + ((long long)g * p.npart + idx) * 2;
         dst[0] = a1; dst[1] = a2;
     }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
     block_to_work(p, b, h, chunk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
     const bool has_bias = pp.ids != nullptr;
-    const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;   // repeat_interleave, :96-99
+    const int bw = has_bias ? fdiv(b * p.H + h, p.fd_rep) : 0;   // repeat_interleave, :96-99
     const bool dbg = STAMPS && (p.flags & 32u) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && p.std_out != nullptr;
     unsigned long long* dbgp = reinterpret_cast<unsigned long long*>(p.std_out) + wave * 64;
     (void)dbg; (void)dbgp;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
     PartialLoads pl;
     float sd = 1.f, sig = 1.f;
     if (has_bias) {
-        pl.issue(p, b % p.n_groups);
+        pl.issue(p, b - fdiv(b, p.fd_ngroups) * p.n_groups);
         sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
     }
     ImgCopy<P::KFR + P::VFR> imgc;
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(kThreads, 2) void xp_stats_long(XpParams pp, int nk
     if (threadIdx.x == 0) {
         double a1 = 0.0, a2 = 0.0;
         for (int w = 0; w < kWaves; ++w) { a1 += red[2 * w]; a2 += red[2 * w + 1]; }
-        const int g = b % p.n_groups;
-        const int idx = ((b / p.n_groups) * p.H + h) * p.nchunks + chunk;
+        const int bg = fdiv(b, p.fd_ngroups), g = b - bg * p.n_groups;
+        const int idx = (bg * p.H + h) * p.nchunks + chunk;
         double* dst = p.partials + ((long long)g * p.npart + idx) * 2;
         dst[0] = a1; dst[1] = a2;
     }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd_long(XpPar
     block_to_work(p, b, h, chunk);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 31, hh = lane >> 5;
     const bool has_bias = pp.ids != nullptr;
-    const int bw = has_bias ? (b * p.H + h) / ((p.Bc * p.H) / p.Bw) : 0;
+    const int bw = has_bias ? fdiv(b * p.H + h, p.fd_rep) : 0;
     const int l0 = (chunk * kWaves + wave) * 32;
     const bool tile_ok = l0 < p.L, row_ok = l0 + r < p.L;
     const int row = tile_ok ? min(l0 + r, p.L - 1) : 0;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd_long(XpPar
     }
     if (has_bias) {
         const float sig = p.sigma_dev ? *p.sigma_dev : p.sigma_host;
-        const float sd = group_std(p, b % p.n_groups, red, false);        // contains __syncthreads()
+        const float sd = group_std(p, b - fdiv(b, p.fd_ngroups) * p.n_groups, red, false);        // contains __syncthreads()
         for (int idx = threadIdx.x; idx < pp.NU * rs; idx += kThreads) {  // w * sigma * std, zero padded past each chunk's keys
             const int u = idx / rs, rem = idx - u * rs, kc = rem / kBP, s_ = rem - kc * kBP;
             const int key = kc * kSMax + s_;

@@ -13,6 +13,21 @@ constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kRedBytes = (2 * kThreads + 32) * 8;       // LDS scratch of the fp64 reductions
 
+// Division of a workgroup index by a launch constant without the ~30-instruction, ~130-cycle dependent chain of a runtime integer
+// division: every xattn kernel starts with three to five of them (batch row from the workgroup id, region-table row, std group),
+// on the critical path in front of its first load.  mg = floor(2^32 / d) + 1 gives floor(n / d) = umulhi(n, mg) exactly while
+// n * d < 2^32 (checked on the host, else mg = 0 and the kernel divides).
+struct FastDiv { int d; unsigned mg; };
+inline FastDiv make_fastdiv(long long d, long long n_max) {
+    FastDiv f;
+    f.d = (int)(d > 0 ? d : 1);
+    f.mg = (f.d > 1 && (unsigned long long)n_max * (unsigned long long)f.d < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)f.d + 1ull) : 0u;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {       // n >= 0
+    return f.d == 1 ? n : (f.mg ? (int)__umulhi((unsigned)n, f.mg) : n / f.d);
+}
+
 struct XattnParams {
     const half_t* q; const half_t* k; const half_t* v; half_t* out;
     const float* region;
@@ -28,15 +43,16 @@ struct XattnParams {
     // the std is taken over scale * q.k^T + mask): fp32, element (bh, l, s) at mask[bh * msbh + l * msl + s]; strides 0 = broadcast
     const float* mask; long long msbh, msl;
     double inv_n, inv_nm1;       // 1 / n and 1 / (n - 1), n = scores per std group (plan_tiles)
+    FastDiv fd_nchunks, fd_ngroups, fd_rep;      // by nchunks, n_groups, (Bc H) / Bw (plan_tiles)
 };
 
 // grid = (8, H, Bc*nchunks/8) when Bc*nchunks % 8 == 0, else (1, H, Bc*nchunks).  The hardware deals linear workgroup
 // ids x + 8*(y + H*z) round-robin over the 8 XCDs, so the H heads (y) of one (b, row chunk) = (z, x) share an XCD and
-// re-read the same region rows / Q lines from that XCD's L2 - with no integer division except b = cg / nchunks.
+// re-read the same region rows / Q lines from that XCD's L2 - with no integer division except b = cg / nchunks (a multiply: FastDiv).
 __device__ __forceinline__ void block_to_work(const XattnParams& p, int& b, int& h, int& chunk) {
     h = blockIdx.y;
     const int cg = blockIdx.z * gridDim.x + blockIdx.x;
-    b = cg / p.nchunks;
+    b = fdiv(cg, p.fd_nchunks);
     chunk = cg - b * p.nchunks;
 }
 inline dim3 xattn_grid(const XattnParams& p) {
@@ -388,6 +404,9 @@ inline void plan_tiles(XattnParams& p, int tiles_per_wave_hint = 0) {
         p.inv_nm1 = 1.0 / (n - 1.0);                          // (a single score: inf, 0 * inf = nan - what torch.std gives)
     }
     p.xcd_map = ((p.Bc * p.nchunks) % 8 == 0) ? 1 : 0;
+    p.fd_nchunks = make_fastdiv(p.nchunks, (long long)p.Bc * p.nchunks);
+    p.fd_ngroups = make_fastdiv(p.n_groups, p.Bc);
+    p.fd_rep = make_fastdiv(((long long)p.Bc * p.H) / (p.Bw > 0 ? p.Bw : 1), (long long)p.Bc * p.H);
 }
 
 }  // namespace dsc_xattn
