@@ -57,6 +57,7 @@ struct ConvParams {
     int order;                    // workgroup order within an XCD (see the kernel)
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
     int mt, nt;                   // tiles along pixels / output channels
+    FastDiv fd_mt, fd_nt, fd_bpi, fd_bpr;   // (plan(): the workgroup's tile, image and sub-block row without runtime divisions)
     long long npix;
     unsigned x_bytes, w_bytes;    // extents for the buffer descriptors
     long long* stamps;            // diagnostics (dsc_debug_set_conv_stamps): 8 x int64 per workgroup, NULL in normal calls
@@ -156,13 +157,13 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
     if (p.stamps) { st0 = __builtin_amdgcn_s_memrealtime(); sc0 = __builtin_amdgcn_s_memtime(); }
     int bm, bn, sp;
     if (p.order) {                                           // channel blocks fastest: one XCD shares a pixel tile's halo
-        bn = v % p.nt;
-        const int rest = v / p.nt;
-        bm = rest % p.mt; sp = rest / p.mt;
+        const int rest = fdiv(v, p.fd_nt);
+        bn = v - rest * p.nt;
+        sp = fdiv(rest, p.fd_mt); bm = rest - sp * p.mt;
     } else {                                                 // pixel tiles fastest: one XCD shares a weight slab
-        bm = v % p.mt;
-        const int rest = v / p.mt;
-        bn = rest % p.nt; sp = rest / p.nt;
+        const int rest = fdiv(v, p.fd_mt);
+        bm = v - rest * p.mt;
+        sp = fdiv(rest, p.fd_nt); bn = rest - sp * p.nt;
     }
     const int n0 = bn * BN;
     const int cb = sp * p.cps, ce = min(p.nc, cb + p.cps);
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
         const int g = bm * NSB + sb;
-        const int b = g / p.bpi, r2 = g - b * p.bpi, byy = r2 / p.bpr;
+        const int b = fdiv(g, p.fd_bpi), r2 = g - b * p.bpi, byy = fdiv(r2, p.fd_bpr);
         ob[sb] = g < p.nblk ? b : -1;            // -1: the tile's last sub-block does not exist
         oy[sb] = byy * 8; ox[sb] = (r2 - byy * p.bpr) * TW;
     }
@@ -537,6 +538,9 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
     if (splits > p->nc) splits = p->nc;
     p->cps = (p->nc + splits - 1) / splits;
     p->splits = (p->nc + p->cps - 1) / p->cps;
+    const long long total = (long long)p->mt * p->nt * p->splits;
+    p->fd_mt = make_fastdiv(p->mt, total); p->fd_nt = make_fastdiv(p->nt, total);
+    p->fd_bpi = make_fastdiv(p->bpi, (long long)p->mt * nsb + nsb); p->fd_bpr = make_fastdiv(p->bpr, p->bpi);
     return tw;
 }
 

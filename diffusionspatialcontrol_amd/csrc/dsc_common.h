@@ -13,6 +13,23 @@ typedef float f2x_t __attribute__((ext_vector_type(2)));
 
 #define DSC_WAVE 64
 
+// Division of a workgroup index by a launch constant without the ~30-instruction, ~130-cycle dependent chain of a runtime integer
+// division (v_rcp_iflag + fix-ups + v_readfirstlane): most kernels start with one to five of them - tile row / column from the
+// workgroup id, image / group / chunk - on the critical path in front of their first load.  mg = floor(2^32 / d) + 1 gives
+// floor(n / d) = umulhi(n, mg) exactly while n * d < 2^32 (checked on the host, else mg = 0 and the kernel divides).
+struct FastDiv { int d; unsigned mg; };
+inline FastDiv make_fastdiv(long long d, long long n_max) {
+    FastDiv f;
+    f.d = (int)(d > 0 ? d : 1);
+    f.mg = (f.d > 1 && n_max >= 0 && (unsigned long long)n_max * (unsigned long long)f.d < (1ull << 32))
+               ? (unsigned)((1ull << 32) / (unsigned)f.d + 1ull) : 0u;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {       // n >= 0
+    return f.d == 1 ? n : (f.mg ? (int)__umulhi((unsigned)n, f.mg) : n / f.d);
+}
+
+
 // v_mfma_f32_32x32x16_f16: D[32x32] += A[32x16] * B[16x32].  Lane l (r = l & 31, hh = l >> 5) holds
 // A[row r][k = 8hh + j] and B[k = 8hh + j][col r] in element j; D element i of lane l is
 // D[row (i & 3) + 8 (i >> 2) + 4 hh][col r]   (cdna_hip_programming.md section 3).

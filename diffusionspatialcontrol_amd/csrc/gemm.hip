@@ -66,6 +66,7 @@ struct GemmParams {
     // dsc_linear_gn_f16: GroupNorm partial sums of the stored tensor (gn_partials.h): rows are pixels, gn_L of them per image
     // (gn_L % BM == 0: a row tile lies in one image), 64-column tiles only
     float* gn_part; int gn_cpg, gn_G, gn_L;
+    FastDiv fd_nb, fd_tiles;     // by the column blocks per row panel and by the tiles per split (linear_impl)
     long long* stamps;           // diagnostics (dsc_debug_set_gemm_stamps): 8 x int64 per workgroup, NULL in normal calls
 };
 
@@ -146,11 +147,11 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     if (p.stamps) { st0 = __builtin_amdgcn_s_memrealtime(); sc0 = __builtin_amdgcn_s_memtime(); }
     int kbeg = 0;                                            // first K tile of this workgroup (split-K)
     if (p.splits > 1) {
-        const int sp = bid / p.tiles;
+        const int sp = fdiv(bid, p.fd_tiles);
         bid -= sp * p.tiles;
         kbeg = sp * p.kps;
     }
-    const int bn = bid % nb, bm = bid / nb;                  // consecutive workgroups share the activation panel
+    const int bm = fdiv(bid, p.fd_nb), bn = bid - bm * nb;   // consecutive workgroups share the activation panel
     const int m0 = bm * BM;
     const int n0 = GEGLU ? bn * (32 * NT) : bn * BNT;
     const int Nh = p.N / 2;
@@ -557,6 +558,8 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
         p.bias = nullptr; p.res = nullptr;
     }
     p.total = p.tiles * p.splits;
+    p.fd_nb = make_fastdiv(nb, p.total);
+    p.fd_tiles = make_fastdiv(p.tiles, p.total);
     const dim3 grid(p.xcd_remap ? ((p.total + 7) / 8) * 8 : p.total), block(T);
     // Two stages (48 KiB: three workgroups per CU instead of two) for grids of many workgroups per CU: with K = 320 / 640 the
     // K loop is a third of a workgroup's time (prologue DMA chain, LayerNorm / GEGLU epilogue), and a third co-resident
@@ -578,6 +581,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     if (wide) {
         nb = N / 128;
         p.total = mb * nb;
+        p.fd_nb = make_fastdiv(nb, p.total);
         size_t wl = (size_t)2 * stage_halves(128, 2) * sizeof(half_t);
         const size_t we = (size_t)128 * epi_stride(2) * sizeof(float) + (size_t)128 * 2 * sizeof(float);
         if (wl < we) wl = we;

@@ -37,6 +37,8 @@ struct GnN {
     // statistics from the PRODUCER of x (dsc_groupnorm_apply_nhwc; gn_partials.h): fpart[b][pt][g][which][2] fp32, fPT pixel
     // tiles per image - the apply pass is then the whole GroupNorm
     const float* fpart; int fPT;
+    // index arithmetic without runtime divisions (dsc_common.h FastDiv; gn_fastdivs() below fills them before every launch)
+    FastDiv fd_G, fd_anchunk, fd_cv, fd_cpg, fd_vpp, fd_nslab, fd_nchunk, fd_scv;
 };
 
 // element (b, pix, channel c .. c+7) of the input; in concatenation mode read from the source that holds c and copied to cat
@@ -54,15 +56,14 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
     // workgroup = (image, row chunk, channel slab); a slab is scv 16-byte vectors = whole groups, so the workgroup owns its
     // groups' partial sums over its rows.  Slabs are the second axis of parallelism: few row chunks (<= 32 partial rows for
     // the apply pass to add up itself, no finalize launch) and still a chip-filling number of workgroups.
-    const int slab = blockIdx.x % p.nslab;
-    const int bc = blockIdx.x / p.nslab;
-    const int b = bc / p.nchunk, chunk = bc % p.nchunk;
+    const int bc = fdiv(blockIdx.x, p.fd_nslab), slab = blockIdx.x - bc * p.nslab;
+    const int b = fdiv(bc, p.fd_nchunk), chunk = bc - b * p.nchunk;
     const int v0 = slab * p.scv;                              // first vector of the slab
     const int sw = min(p.scv, p.cv - v0);                     // this slab's width in vectors (the last one may be narrower)
     const int SC = p.scv * 8;                                 // LDS row pitch in channels
     float* ssum = reinterpret_cast<float*>(smem);            // [sk][SC]
     float* ssq = ssum + p.sk * SC;                           // [sk][SC]
-    const int lv = threadIdx.x % p.scv, slice = threadIdx.x / p.scv;
+    const int slice = fdiv(threadIdx.x, p.fd_scv), lv = threadIdx.x - slice * p.scv;
     const bool live = lv < sw;
     const int c8 = v0 + lv;
     const int r0 = chunk * p.rows, r1 = min(r0 + p.rows, p.HW);
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_stats(GnN p) {
 
 // one wave per (image, group): lane i adds chunk partials i, i+64, ... (fixed order), then a fixed-order butterfly
 __global__ __launch_bounds__(64) void gn_nhwc_finalize(GnN p) {
-    const int b = blockIdx.x / p.G, g = blockIdx.x % p.G;
+    const int b = fdiv(blockIdx.x, p.fd_G), g = blockIdx.x - b * p.G;
     const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
     double a1 = 0.0, a2 = 0.0;
     for (int i = threadIdx.x; i < p.nchunk; i += 64) { a1 += src[(long long)i * p.G * 2]; a2 += src[(long long)i * p.G * 2 + 1]; }
@@ -151,18 +152,18 @@ __global__ __launch_bounds__(64) void gn_nhwc_finalize(GnN p) {
 __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     __shared__ float mean_s[64], rstd_s[64];
     __shared__ double red[8 * 64 * 2];
-    const int b = blockIdx.x / p.anchunk, chunk = blockIdx.x % p.anchunk;
+    const int b = fdiv(blockIdx.x, p.fd_anchunk), chunk = blockIdx.x - b * p.anchunk;
     // Every load this workgroup's first rows need is issued up front, in the order the values are needed (a wave's loads
     // return in order): the statistics partials, the channel constants, then the first rows - so the partial sums are being
     // added while the rows are still in flight, and nothing is fetched behind a barrier.
     constexpr int kPre = 4, kPL = 5;                          // rows / partial rows per thread in flight
-    const int c8 = threadIdx.x % p.cv, slice = threadIdx.x / p.cv;
+    const int slice = fdiv(threadIdx.x, p.fd_cv), c8 = threadIdx.x - slice * p.cv;
     const int r0 = chunk * p.arows, r1 = min(r0 + p.arows, p.HW);
     const long long off = (long long)b * p.HW * p.C + c8 * 8;
     // few statistics chunks (<= 32 per image): every apply workgroup adds them itself, in a fixed order - 16 KB of
     // L2 reads instead of a third launch.  thread (g, part): chunks part, part + P, ...; then the P parts in order
-    const int P = min(8, (int)blockDim.x / p.G);
-    const int g = threadIdx.x % p.G, part = threadIdx.x / p.G;
+    const int P = min(8, fdiv((int)blockDim.x, p.fd_G));
+    const int part = fdiv(threadIdx.x, p.fd_G), g = threadIdx.x - part * p.G;
     const double* src = p.partials + ((long long)b * p.nchunk * p.G + g) * 2;
     double pl1[kPL], pl2[kPL];
     // producer partials: group g's sums over pixel tile i are slot (g, 0) plus, when the group straddles a 64-channel tile
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
     {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int gg = (c8 * 8 + j) / p.cpg;
+            const int gg = fdiv(c8 * 8 + j, p.fd_cpg);
             sc[j] = (float)ga[j] * rstd_s[gg];
             sh[j] = (float)be[j] + ((float)ad[j] - mean_s[gg]) * sc[j];
         }
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(kMaxT) void gn_nhwc_apply(GnN p) {
 constexpr int kSmallVec = 8;
 __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
     __shared__ float red[8];
-    const int b = blockIdx.x / p.G, g = blockIdx.x % p.G;
+    const int b = fdiv(blockIdx.x, p.fd_G), g = blockIdx.x - b * p.G;
     const int vpp = p.cpg >> 3;                               // vectors per pixel of this group
     const int nvec = p.HW * vpp;
     const long long base = (long long)b * p.HW * p.C + g * p.cpg;
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
     for (int i = 0; i < kSmallVec; ++i) {
         const int idx = threadIdx.x + 256 * i;
         if (idx < nvec) {
-            const int pix = idx / vpp, j8 = idx - pix * vpp;
+            const int pix = fdiv(idx, p.fd_vpp), j8 = idx - pix * vpp;
             const h8_t x = gn_load(p, b, pix, g * p.cpg + j8 * 8);
             h8_t ad = {0, 0, 0, 0, 0, 0, 0, 0};
             if (p.add) ad = *reinterpret_cast<const h8_t*>(p.add + (long long)b * p.add_stride + g * p.cpg + j8 * 8);
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_small(GnN p) {
     for (int i = 0; i < kSmallVec; ++i) {
         const int idx = threadIdx.x + 256 * i;
         if (idx < nvec) {
-            const int pix = idx / vpp, j8 = idx - pix * vpp;
+            const int pix = fdiv(idx, p.fd_vpp), j8 = idx - pix * vpp;
             const h8_t ga = gav[i], be = bev[i];
             h8_t o;
 #pragma unroll
@@ -495,6 +496,15 @@ bool plan(GnN& p) {
     return true;
 }
 
+// every divisor the kernels' index arithmetic uses, as a multiply (indices stay far below 2^32 / divisor: thread ids, grid sizes)
+void gn_fastdivs(GnN& p) {
+    const long long big = 1ll << 20;
+    p.fd_G = make_fastdiv(p.G, big); p.fd_anchunk = make_fastdiv(p.anchunk > 0 ? p.anchunk : 1, big);
+    p.fd_cv = make_fastdiv(p.cv > 0 ? p.cv : 1, big); p.fd_cpg = make_fastdiv(p.cpg > 0 ? p.cpg : 1, big);
+    p.fd_vpp = make_fastdiv(p.cpg >= 8 ? p.cpg >> 3 : 1, big); p.fd_nslab = make_fastdiv(p.nslab > 0 ? p.nslab : 1, big);
+    p.fd_nchunk = make_fastdiv(p.nchunk > 0 ? p.nchunk : 1, big); p.fd_scv = make_fastdiv(p.scv > 0 ? p.scv : 1, big);
+}
+
 int g_gn_mode = 0;   // diagnostics (dsc_debug_set_gn_mode): 0 auto, 2 never a single-launch kernel, 3 also the 1024-thread bundle kernel, 4 = 2 + separate finalize launch
 
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -586,6 +596,7 @@ int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, con
     p.eps = eps; p.silu = apply_silu;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (p.cpg % 8 == 0 && (long long)p.HW * (p.cpg / 8) <= 256 * kSmallVec && g_gn_mode != 2) {      // small image: single launch
+        gn_fastdivs(p);
         DSC_LAUNCH(gn_nhwc_small, dim3(B * groups), dim3(256), 0, st, p);
         return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
     }
@@ -612,6 +623,7 @@ int run_groupnorm(const void* x, const void* x2, int C1, void* cat, void* y, con
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_nhwc_stats), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     }
+    gn_fastdivs(p);
     DSC_LAUNCH(gn_nhwc_stats, dim3(B * p.nchunk * p.nslab), dim3(p.scv * p.sk), stats_lds, st, p);
     if (!p.inline_stats) DSC_LAUNCH(gn_nhwc_finalize, dim3(B * groups), dim3(64), 0, st, p);
     if (p.x2) { p.x = p.cat; p.x2 = nullptr; }                  // the statistics pass wrote the concatenation: apply streams it
@@ -634,6 +646,7 @@ extern "C" int dsc_groupnorm_apply_nhwc(const void* x, void* y, const void* gamm
     p.gamma = static_cast<const half_t*>(gamma); p.beta = static_cast<const half_t*>(beta);
     p.eps = eps; p.silu = apply_silu;
     p.fpart = gn_part; p.fPT = part_rows; p.inline_stats = 1;
+    gn_fastdivs(p);
     DSC_LAUNCH(gn_nhwc_apply, dim3(B * p.anchunk), dim3(p.cv * p.k), 0, static_cast<hipStream_t>(stream), p);
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }

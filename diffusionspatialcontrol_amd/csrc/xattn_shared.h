@@ -13,21 +13,6 @@ constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr int kRedBytes = (2 * kThreads + 32) * 8;       // LDS scratch of the fp64 reductions
 
-// Division of a workgroup index by a launch constant without the ~30-instruction, ~130-cycle dependent chain of a runtime integer
-// division: every xattn kernel starts with three to five of them (batch row from the workgroup id, region-table row, std group),
-// on the critical path in front of its first load.  mg = floor(2^32 / d) + 1 gives floor(n / d) = umulhi(n, mg) exactly while
-// n * d < 2^32 (checked on the host, else mg = 0 and the kernel divides).
-struct FastDiv { int d; unsigned mg; };
-inline FastDiv make_fastdiv(long long d, long long n_max) {
-    FastDiv f;
-    f.d = (int)(d > 0 ? d : 1);
-    f.mg = (f.d > 1 && (unsigned long long)n_max * (unsigned long long)f.d < (1ull << 32)) ? (unsigned)((1ull << 32) / (unsigned)f.d + 1ull) : 0u;
-    return f;
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {       // n >= 0
-    return f.d == 1 ? n : (f.mg ? (int)__umulhi((unsigned)n, f.mg) : n / f.d);
-}
-
 struct XattnParams {
     const half_t* q; const half_t* k; const half_t* v; half_t* out;
     const float* region;
