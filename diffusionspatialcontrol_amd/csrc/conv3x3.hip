@@ -57,6 +57,7 @@ struct ConvParams {
     int order;                    // workgroup order within an XCD (see the kernel)
     int bpr, bpi, nblk;           // sub-blocks per image row / per image / in total
     int mt, nt;                   // tiles along pixels / output channels
+    FastDiv fd_cv;                // conv3x3_reduce: by the 8-channel vectors per pixel
     FastDiv fd_mt, fd_nt, fd_bpi, fd_bpr;   // (plan(): the workgroup's tile, image and sub-block row without runtime divisions)
     long long npix;
     unsigned x_bytes, w_bytes;    // extents for the buffer descriptors
@@ -459,11 +460,14 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
 
 // out = sum over splits (in split order) + bias + residual, one fp16 rounding
 __global__ __launch_bounds__(256) void conv3x3_reduce(ConvParams p) {
-    const int cv = p.Cout / 8;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.onpix * cv) return;
-    const long long gp = idx / cv;
-    const int n = (int)(idx % cv) * 8;
+    // (32-bit indices - the entry point bounds pixels x channels below 2^30 - and the division by the vectors per pixel as a
+    // multiply: as a 64-bit `idx / cv` it was a ~150-instruction software division at the head of a 5 us kernel)
+    const int cv = p.Cout >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int)p.onpix * cv) return;
+    const int gpi = fdiv(idx, p.fd_cv);
+    const long long gp = gpi;
+    const int n = (idx - gpi * cv) * 8;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < p.splits; ++k) {
         const float* src = p.ws + ((long long)k * p.onpix + gp) * p.Cout + n;
@@ -685,6 +689,7 @@ int conv_impl(const void* x, const void* w, const void* bias, const void* residu
     if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     if (p.splits > 1) {
         const long long n = p.onpix * (Cout / 8);
+        p.fd_cv = make_fastdiv(Cout / 8, n + 256);
         DSC_LAUNCH(conv3x3_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
         if (hipGetLastError() != hipSuccess) return DSC_ERR_LAUNCH;
     }

@@ -409,12 +409,12 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
 
 // out = sum over the splits (in split order) + bias + residual, one fp16 rounding (the second launch of dsc_linear_splitk_f16)
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(const float* ws, const half_t* bias, const half_t* res, half_t* out,
-                                                          long long M, int N, int splits, long long ldr, long long ldo) {
-    const int cv = N / 8;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= M * cv) return;
-    const long long m = idx / cv;
-    const int n = (int)(idx - m * cv) * 8;
+                                                          long long M, int N, int splits, long long ldr, long long ldo, FastDiv fd_cv) {
+    const int cv = N >> 3;
+    const int idx = blockIdx.x * 256 + threadIdx.x;           // (M <= 512 rows here: 32-bit, and the division a multiply)
+    if (idx >= (int)M * cv) return;
+    const long long m = fdiv(idx, fd_cv);
+    const int n = (idx - (int)m * cv) * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int k = 0; k < splits; ++k) {
         const float* src = ws + ((long long)k * M + m) * N + n;
@@ -684,8 +684,9 @@ extern "C" int dsc_linear_splitk_f16(const void* x, const void* w, const void* b
                                nullptr, 0, 0, splits, static_cast<float*>(workspace));
     if (rc != DSC_OK) return rc;
     const long long n8 = M * (N / 8);
+    if (n8 >= (1ll << 30)) return DSC_ERR_UNSUPPORTED;          // the reduce kernel indexes with 32 bits
     DSC_LAUNCH(gemm_splitk_reduce, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                static_cast<const float*>(workspace), static_cast<const half_t*>(bias), static_cast<const half_t*>(residual),
-               static_cast<half_t*>(out), (long long)M, N, splits, (long long)ldr, (long long)ldo);
+               static_cast<half_t*>(out), (long long)M, N, splits, (long long)ldr, (long long)ldo, make_fastdiv(N / 8, n8 + 256));
     return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
 }
