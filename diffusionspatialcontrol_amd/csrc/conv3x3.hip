@@ -342,12 +342,14 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
                 acc[1] = mfma_32x32x16(cur.w[ks], cur.x1[ks], acc[1]);
             }
             // issue order within the step (the loop is instruction-issue bound: one wave per SIMD, and a 32-cycle MFMA
-            // hides ~24 cycles of other issue): the next fragments' 12 LDS reads ride in the first four MFMA gaps so
-            // the last four MFMAs cover their latency; the DMAs (1 KiB each, ~60 cycles of issue) one per gap
+            // hides ~24 cycles of other issue): the next fragments' 12 LDS reads ride two per gap in the first six MFMA
+            // gaps, the last two MFMAs cover their latency (a ds_read_b128 costs ~16 issue cycles: three per gap in four
+            // gaps - round 2 - made those gaps 56 cycles; in the step <16, 3, 0> 35.4 -> 34.1 us, <16, 9, 4> 30.1 -> 29.8;
+            // 2,2,2,2,1,1,1,1 and 2,1,2,1,... are no better: 34.6-34.7); the DMAs (1 KiB each, ~60 cycles of issue) one per gap
             if (!LOADER) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);    // VMEM read (first DMA piece)
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                if (g < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // DS read
+                if (g < 6) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);               // MFMA
                 if (!LOADER && g < (t == 0 ? 8 : 1)) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
             }
