@@ -67,6 +67,9 @@ struct GemmParams {
     // (gn_L % BM == 0: a row tile lies in one image), 64-column tiles only
     float* gn_part; int gn_cpg, gn_G, gn_L;
     FastDiv fd_nb, fd_tiles;     // by the column blocks per row panel and by the tiles per split (linear_impl)
+    // a residual of fewer rows than M (a residual stream computed once per image under the shared CFG prefix, added to a result
+    // that has a row per CFG branch): row m adds residual row m % res_rows; res_rows % BM == 0, so a row tile lies in one copy
+    int res_rows; FastDiv fd_res;
     long long* stamps;           // diagnostics (dsc_debug_set_gemm_stamps): 8 x int64 per workgroup, NULL in normal calls
 };
 
@@ -265,13 +268,14 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     // residual rows of this thread's four output chunks: issued before the staging pass so that their latency (HBM /
     // Infinity Cache: the residual stream was written by an earlier kernel) hides under it
     constexpr int NCH = BM * CR / T;                         // output chunks per thread: 4 or 2 (8 / 4 with NT = 2)
+    const int mres0 = p.res_rows ? m0 - fdiv(m0, p.fd_res) * p.res_rows : m0;     // (scalar) first residual row of this tile
     h8_t rpre[NCH];
     if (!GEGLU) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int idx = threadIdx.x + c * T, row = idx / CR, ch = idx % CR;
             rpre[c] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            if (p.res && m0 + row < p.M) rpre[c] = *reinterpret_cast<const h8_t*>(p.res + (long long)(m0 + row) * p.ldr + n0 + ch * 8);
+            if (p.res && m0 + row < p.M) rpre[c] = *reinterpret_cast<const h8_t*>(p.res + (long long)(mres0 + row) * p.ldr + n0 + ch * 8);
         }
     }
     __syncthreads();                                         // all MFMA operand reads done: LDS becomes the epilogue stage
@@ -503,6 +507,10 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     if (ln_in && !al16(ln_cvec)) return DSC_ERR_UNSUPPORTED;       // read as float4 pairs
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
     if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
+    // ldr: low 32 bits = the residual's row stride; high 32 bits, when set, = its row count R < M (include/dsc_hip.h)
+    const int64_t res_rows = residual ? (ldr >> 32) : 0;
+    ldr &= 0xffffffffll;
+    if (res_rows < 0 || (res_rows > 0 && (M % res_rows != 0 || res_rows % 128 != 0 || splits > 1))) return DSC_ERR_UNSUPPORTED;
     if (K % BK != 0 || N % BN != 0 || ldx % 8 != 0 || ldo % 8 != 0 || (residual && ldr % 8 != 0)) return DSC_ERR_UNSUPPORTED;
     if (geglu && (!bias || residual || (N / 2) % 32 != 0)) return DSC_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(w) || !al16(out) || (bias && !al16(bias)) || (residual && !al16(residual))) return DSC_ERR_UNSUPPORTED;
@@ -513,6 +521,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     p.bias = static_cast<const half_t*>(bias); p.res = static_cast<const half_t*>(residual);
     p.out = static_cast<half_t*>(out);
     p.M = (int)M; p.N = N; p.K = K; p.ldx = ldx; p.ldr = ldr; p.ldo = ldo;
+    p.res_rows = (int)res_rows; p.fd_res = make_fastdiv(res_rows > 0 ? res_rows : 1, M);
     p.ln_in = ln_in; p.ln_c = ln_cvec; p.ln_out = ln_out; p.ln_nb = ln_nb; p.ln_inv_c = 1.f / (float)K; p.ln_eps = ln_eps;
     if (kv_out) {
         p.kv = static_cast<half_t*>(kv_out);
@@ -677,6 +686,7 @@ extern "C" int dsc_linear_splitk_f16(const void* x, const void* w, const void* b
     const int nkt = K / BK, kps = (nkt + splits - 1) / splits;
     splits = (nkt + kps - 1) / kps;
     if (splits <= 1) return dsc_linear_f16(x, w, bias, residual, out, M, N, K, ldx, ldr, ldo, 0, dtype, stream);
+    if (residual && (ldr >> 32) != 0) return DSC_ERR_UNSUPPORTED;      // (a wrapped residual: the unsplit kernel only)
     const size_t need = (size_t)splits * M * N * sizeof(float);
     if (!workspace || workspace_bytes < need || !al16(workspace)) return DSC_ERR_WORKSPACE;
     if ((bias && !al16(bias)) || (residual && (!al16(residual) || ldr % 8 != 0)) || ldo % 8 != 0 || !al16(out)) return DSC_ERR_UNSUPPORTED;

@@ -402,7 +402,9 @@ class _RegionProcessor:
         if _ln_fold is not None:
             # the block's `x = attn(norm(x)) + x` add and the next LayerNorm's row statistics ride in this GEMM's epilogue
             res = _ln_fold.residual
-            if res.shape[0] != hidden_states.shape[0]:       # shared CFG prefix: the residual stream was computed once per image
+            if res.shape[0] != hidden_states.shape[0] and ((res.shape[0] * res.shape[1]) % 128 != 0 or not ops.USE_RESIDUAL_WRAP):
+                # shared CFG prefix: the residual stream was computed once per image.  The GEMM wraps a residual of fewer rows
+                # itself (dsc_linear_f16: row m adds residual row m % R) when R is a multiple of its row tiles; else repeat
                 res = res.repeat(hidden_states.shape[0] // res.shape[0], 1, 1)
             return ops.linear_ln(hidden_states, to_out.weight, to_out.bias, residual=res, ln_stats=True)
         hidden_states = ops.linear(hidden_states, to_out.weight, to_out.bias) if type(to_out) is nn.Linear \

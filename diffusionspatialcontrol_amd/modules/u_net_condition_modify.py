@@ -537,7 +537,9 @@ class Transformer2DModel(nn.Module):
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, encoder_hidden_states, cross_attention_kwargs, stats=st if i == 0 else None)
         res = _tokens(x)
-        if res.shape[0] != t.shape[0]:                           # shared CFG prefix: x came in once per image
+        if res.shape[0] != t.shape[0] and not (res.is_cuda and ops.USE_RESIDUAL_WRAP and (res.shape[0] * res.shape[1]) % 128 == 0):
+            # shared CFG prefix: x came in once per image.  (On the GPU the GEMM wraps a residual of fewer rows itself:
+            # ops.linear / linear_gn, dsc_linear_f16.)
             res = res.repeat(t.shape[0] // res.shape[0], 1, 1)
         if self.use_linear_projection:
             t = ops.linear(t, self.proj_out.weight, self.proj_out.bias, residual=res)

@@ -428,13 +428,33 @@ def linear_gn(x, weight, bias, residual, rows_per_image, groups):
     if rows <= 0 or not linear_kernel_can(x, weight, bias, residual):
         return None
     x2 = x.reshape(M, K)
-    r2 = residual.reshape(M, N) if residual is not None else None
+    r2, ldr = _residual_2d(residual, M, N) if residual is not None else (None, 0)
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     part = torch.empty((B, rows, groups, 2, 2), dtype=torch.float32, device=x.device)
     rc = lib.dsc_linear_gn_f16(_p(x2), _p(weight), _p(bias), _p(r2), _p(out), M, N, K, x2.stride(0),
-                               r2.stride(0) if r2 is not None else 0, N, rows_per_image, _p(part), groups, 0, _stream_ptr(x))
+                               ldr, N, rows_per_image, _p(part), groups, 0, _stream_ptr(x))
     _lib.check(rc, "dsc_linear_gn_f16")
     return out.reshape(B, L, N), GnPartials(part, rows, groups, N, B, L)
+
+
+USE_RESIDUAL_WRAP = os.environ.get("DSC_RESIDUAL_WRAP", "1") != "0"   # (A/B switch: 0 = repeat a shorter residual on the host, as before)
+
+
+def _residual_2d(residual, M, N):
+    """(r2, ldr) for the GEMM entry points: the residual as [R, N] rows and its row stride, with R << 32 in the stride's high
+    bits when it has fewer rows than the result (include/dsc_hip.h, dsc_linear_f16: row m adds residual row m % R - a residual
+    stream computed once per image under the shared CFG prefix); None when the shape is not one the kernels take."""
+    R = residual.numel() // N
+    if R * N != residual.numel() or R <= 0 or M % R != 0:
+        return None
+    r2 = residual.reshape(R, N)
+    if r2.stride(1) != 1 or r2.stride(0) % 8 != 0 or r2.data_ptr() % 16 != 0:
+        return None
+    if R == M:
+        return r2, r2.stride(0)
+    if R % 128 != 0 or not USE_RESIDUAL_WRAP:
+        return None
+    return r2, r2.stride(0) | (R << 32)
 
 
 def linear_kernel_can(x, weight, bias, residual):
@@ -449,10 +469,8 @@ def linear_kernel_can(x, weight, bias, residual):
         return False
     if bias is not None and (bias.dtype != torch.float16 or bias.data_ptr() % 16 != 0):
         return False
-    if residual is not None:
-        r2 = residual.reshape(M, N)
-        if not (r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0):
-            return False
+    if residual is not None and _residual_2d(residual, M, N) is None:
+        return False
     return True
 
 
@@ -553,11 +571,12 @@ def linear_ln(x, weight, bias, *, residual=None, geglu=False, ln=None, ln_stats=
     x2 = x.reshape(M, K)
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or not weight.is_contiguous():
         raise ValueError("linear_ln: unit inner stride, 16-byte aligned rows and a contiguous weight are required")
-    r2 = None
+    r2, ldr = None, 0
     if residual is not None:
-        r2 = residual.reshape(M, N)
-        if r2.stride(1) != 1 or r2.stride(0) % 8 != 0:
-            raise ValueError("linear_ln: residual rows must be 16-byte aligned with unit inner stride")
+        got = _residual_2d(residual, M, N)
+        if got is None:
+            raise ValueError("linear_ln: residual rows must be 16-byte aligned with unit inner stride (M rows, or M / k rows in multiples of 128)")
+        r2, ldr = got
     n_out = N // 2 if geglu else N
     out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
     stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device) if ln_stats else None
@@ -568,7 +587,7 @@ def linear_ln(x, weight, bias, *, residual=None, geglu=False, ln=None, ln_stats=
         if part.shape[0] != M or part.dtype != torch.float32 or not part.is_contiguous() or cvec.numel() != N:
             raise ValueError("linear_ln: statistics / cvec do not match the operands")
     rc = _lib.load_library().dsc_linear_ln_f16(_p(x2), _p(weight), _p(bias), _p(r2), _p(out), M, N, K, x2.stride(0),
-                                               r2.stride(0) if r2 is not None else 0, n_out, 1 if geglu else 0,
+                                               ldr, n_out, 1 if geglu else 0,
                                                _p(part), nb, _p(cvec), float(eps), _p(stats), 0, _stream_ptr(x))
     _lib.check(rc, "dsc_linear_ln_f16")
     out = out.reshape(*lead, n_out)
@@ -655,9 +674,18 @@ def linear(x, weight, bias=None, residual=None, geglu=False, prefer_kernel=False
     if can:
         x2 = x.reshape(M, K)                      # a view when the leading dims collapse (the token-major case)
         can = x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
+    ldr = 0
+    if residual is not None and residual.numel() != M * N:
+        # fewer residual rows than result rows (shared CFG prefix): the kernel wraps them (dsc_linear_f16), every other route
+        # gets them repeated
+        got = _residual_2d(residual, M, N) if can and not geglu else None
+        if got is None or not (prefer_kernel or _gemm_rows_k_preferred(M, K, geglu)):
+            residual = residual.reshape(-1, N).repeat(M // (residual.numel() // N), 1).reshape(*lead, N)
     if can and residual is not None:
-        r2 = residual.reshape(M, N)
-        can = r2.stride(1) == 1 and r2.stride(0) % 8 == 0 and r2.data_ptr() % 16 == 0
+        got = _residual_2d(residual, M, N)
+        can = got is not None
+        if can:
+            r2, ldr = got
     ok = can and (prefer_kernel or _gemm_rows_k_preferred(M, K, geglu))
     if can and not ok and not geglu and USE_SPLITK and not USE_LIBRARY_GEMM and M <= SPLITK_MAX_ROWS and K >= SPLITK_MIN_K \
             and (bias is None or (bias.dtype == torch.float16 and bias.data_ptr() % 16 == 0)):
@@ -693,7 +721,7 @@ def linear(x, weight, bias=None, residual=None, geglu=False, prefer_kernel=False
     n_out = N // 2 if geglu else N
     out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
     rc = _lib.load_library().dsc_linear_f16(_p(x2), _p(weight), _p(bias), _p(r2) if residual is not None else None, _p(out),
-                                            M, N, K, x2.stride(0), r2.stride(0) if residual is not None else 0, n_out,
+                                            M, N, K, x2.stride(0), ldr if residual is not None else 0, n_out,
                                             1 if geglu else 0, 0, _stream_ptr(x))
     _lib.check(rc, "dsc_linear_f16")
     return out.reshape(*lead, n_out)

@@ -247,6 +247,10 @@ int dsc_add_bias_residual(const void* a, const void* b, const void* bias, void* 
  *   geglu == 1:  out[m, j] = (acc[m,j] + bias[j]) * gelu(acc[m,N/2+j] + bias[N/2+j]),      out is [M, N/2]
  * x [M, K] with row stride ldx, w [N, K] contiguous (torch Linear layout), residual / out with row strides ldr / ldo.
  * Requirements: fp16, K % 64 == 0, N % 64 == 0, strides % 8 == 0, 16-byte aligned pointers; geglu needs bias, no residual.
+ * A residual of FEWER rows than M - the residual stream of layers that ran once per image in front of the first cross-attention,
+ * added to a result that has a row per classifier-free-guidance branch (the reference repeats nothing there: its batch is
+ * already doubled) - is passed as  ldr = row stride | (R << 32)  with R = its row count: row m adds residual row m % R.
+ * R % 128 == 0, M % R == 0; same encoding in dsc_linear_ln_f16 and dsc_linear_gn_f16.  High bits 0: a residual of M rows.
  */
 int dsc_linear_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                    int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu, int dtype, void* stream);

@@ -174,6 +174,35 @@ def test_self_attention_tiling_variants(ops, variant, B, H, L, d):
     assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("M,R,N,K", [(8192, 4096, 320, 320), (2048, 1024, 640, 640), (768, 256, 1280, 1280), (8192, 2048, 320, 1280)])
+def test_linear_wraps_a_residual_of_fewer_rows(ops, M, R, N, K):
+    """dsc_linear_f16 / _ln_f16 / _gn_f16 with ldr = stride | (R << 32): row m adds residual row m % R (the residual stream of the
+    layers in front of the first cross-attention exists once per image, the result once per CFG branch) - the same bytes as with
+    the residual repeated"""
+    g = torch.Generator().manual_seed(M + R + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).half().cuda()
+    b = torch.randn(N, generator=g).half().cuda()
+    r = torch.randn(R, N, generator=g).half().cuda()
+    full = r.repeat(M // R, 1)
+    a = ops.linear(x, w, b, residual=r, prefer_kernel=True)
+    e = ops.linear(x, w, b, residual=full, prefer_kernel=True)
+    assert torch.equal(a, e)
+    a_ln, st_a = ops.linear_ln(x, w, b, residual=r, ln_stats=True)
+    e_ln, st_e = ops.linear_ln(x, w, b, residual=full, ln_stats=True)
+    assert torch.equal(a_ln, e_ln) and torch.equal(st_a, st_e)
+    if M >= 1024:
+        got_a = ops.linear_gn(x.view(2, M // 2, K), w, b, r.view(1, R, N) if M // 2 == R else r, M // 2, 32)
+        got_e = ops.linear_gn(x.view(2, M // 2, K), w, b, full.view(2, M // 2, N), M // 2, 32)
+        if got_a is not None and got_e is not None:
+            assert torch.equal(got_a[0], got_e[0]) and torch.equal(got_a[1].buf[..., 0, :], got_e[1].buf[..., 0, :])   # (slot 1: straddling groups only)
+    # a row count the tiles cannot wrap: repeated on the host, same result
+    r_odd = torch.randn(M // 2 if (M // 2) % 128 else 64, N, generator=g).half().cuda()
+    if M % r_odd.shape[0] == 0:
+        assert torch.equal(ops.linear(x, w, b, residual=r_odd, prefer_kernel=True),
+                           ops.linear(x, w, b, residual=r_odd.repeat(M // r_odd.shape[0], 1), prefer_kernel=True))
+
+
 @pytest.mark.parametrize("S", [1, 3, 4, 5, 59, 60, 61, 63, 64, 65, 67, 68, 69, 124, 127, 128, 129, 132])
 @pytest.mark.parametrize("d,L", [(40, 4096), (64, 96)])
 def test_attention_key_count_edges(ops, S, d, L):
