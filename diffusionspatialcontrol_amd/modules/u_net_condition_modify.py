@@ -717,11 +717,11 @@ class _EncoderHalf:
             return ops.conv3x3_fewcin(sample, wt, ci.bias, ci.out_channels)   # NCHW latents -> NHWC features, one launch
         return ci(sample.contiguous()).contiguous(memory_format=torch.channels_last)
 
-    def _run_down(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs, intrablock=None):
+    def _run_down(self, x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs, intrablock=None, skip0=None):
         """intrablock: T2I-Adapter features, one per down block (reference :1194-1230): added after the LAST resnet /
         attention pair of a cross-attention block (so the skip tensor carries it), after the whole block otherwise"""
         intrablock = None if intrablock is None else list(intrablock)
-        skips = [x]
+        skips = [x if skip0 is None else skip0]                      # (skip0: conv_in's output for the WHOLE batch when x is its shared half)
         for blk in self.down_blocks:
             extra = intrablock.pop(0) if intrablock else None
             last = len(blk.resnets) - 1
@@ -902,14 +902,19 @@ class UNet2DConditionModel(_EncoderHalf, nn.Module, UNet2DConditionLoadersMixin_
         share = bool(cfg_shared_prefix) and sample.shape[0] % 2 == 0 and down_block_additional_residuals is None \
             and down_intrablock_additional_residuals is None and self.down_blocks[0].has_attn \
             and not isinstance(encoder_hidden_states, tuple) and self._first_block_repeats_shared_rows()
-        x = self._conv_in(sample[:sample.shape[0] // 2] if share else sample)
+        # (conv_in itself runs on the whole batch: its output is the first skip tensor, which the up path wants per row - a second
+        # image through the 4-channel convolution costs less than repeating the 320-channel result afterwards)
+        x = self._conv_in(sample)
+        skip0 = x
+        if share:
+            x = x[:sample.shape[0] // 2]
         tadd = self._temb_views(temb_adds) if temb_adds is not None else self._all_temb_adds(temb_act)
         if down_intrablock_additional_residuals is None and mid_block_additional_residual is None \
                 and down_block_additional_residuals is not None:
             # legacy T2I-Adapter usage (reference :1200-1211): residuals without a mid residual are intra-block ones
             down_intrablock_additional_residuals, down_block_additional_residuals = down_block_additional_residuals, None
         skips, x = self._run_down(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs,
-                                  intrablock=down_intrablock_additional_residuals)
+                                  intrablock=down_intrablock_additional_residuals, skip0=skip0)
         if down_block_additional_residuals is not None:          # ControlNet hook (reference :1236-1245)
             skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
         x = self._run_mid(x, temb_act, tadd, encoder_hidden_states, cross_attention_kwargs)
