@@ -83,7 +83,9 @@ def parse():
     ap.add_argument("--decode", action="store_true",
                     help="also run the VAE decoder (SURVEY.md 8f rank 1) inside the timed region; off by default so the "
                          "headline stays the denoising path of BASELINE.json")
-    ap.add_argument("--cpu-sample-steps", type=int, default=3)
+    ap.add_argument("--cpu-sample-steps", type=int, default=25,
+                    help="denoising steps of the cpu_baseline leg (oracle on the host cores): all 25 by default (BASELINE.md section 2: "
+                         "configs[1] timed in full, about two minutes on 16 cores); fewer -> extrapolated and labelled as such")
     return ap.parse_args()
 
 
@@ -147,9 +149,60 @@ def graph_launch_time_us(fn, launches=50, replays=10):
     return start.elapsed_time(end) / (launches * replays) * 1e3
 
 
+def csrc_sha16():
+    """identifies the kernel sources the stamped files under profiles/ (in_step_kernels.json, pmc_mfma_busy.json) were measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "diffusionspatialcontrol_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode() + b"\0" + open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+_STAMPED = {}
+
+
+def stamped(name):
+    """profiles/<name> if it was measured on the kernel sources of this tree (its csrc_sha16 matches), else None"""
+    if name not in _STAMPED:
+        rec = None
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if rec.get("csrc_sha16") != csrc_sha16():
+                rec = None
+        except Exception:  # noqa: BLE001
+            rec = None
+        _STAMPED[name] = rec
+    return _STAMPED[name]
+
+
+def in_step_us(key):
+    """average duration of a kernel INSIDE the captured UNet step (tools/make_in_step.py on a rocprofv3 kernel trace of this
+    command, committed as profiles/in_step_kernels.json); None when the kernels have changed since it was taken"""
+    rec = stamped("in_step_kernels.json")
+    try:
+        return rec["kernels"][key]["in_step"]["avg_us"]
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def mfma_busy(prefix):
+    """{mfma_busy_pct, ..of_occupied_simds} of the first kernel whose name starts with `prefix` in profiles/pmc_mfma_busy.json
+    (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES ... -- python3 tools/pmc_kernels.py, tools/make_mfma_busy.py)"""
+    rec = stamped("pmc_mfma_busy.json")
+    if rec:
+        for k, v in rec["kernels"].items():
+            if k.startswith(prefix):
+                return {"kernel": k, "mfma_busy_pct": v["mfma_busy_pct"],
+                        "mfma_busy_pct_of_occupied_simds": v["mfma_busy_pct_of_occupied_simds"]}
+    return None
+
+
 def roofline_region_xattn(dev, n_img):
-    """The region cross-attention forward kernel (`xp_fwd`, prepared-operand path the pipeline runs) at the L=4096 level
-    of the workload (C=320, H=8, d=40, S=77), Bc = 2*n_img rows.  HBM-bound by arithmetic intensity (61 FLOP/B)."""
+    """The region cross-attention OP (the std over the scores is part of it) on the prepared-operand path the
+    pipeline runs, at the L=4096 level of the workload (C=320, H=8, d=40, S=77), Bc = 2*n_img rows: the statistics launch
+    (`xp_stats`) + the forward launch (`xp_fwd`).  HBM-bound by arithmetic intensity (61 FLOP/B).  `frac` is the OP's: the
+    algorithmic bytes of SURVEY.md 8d over the time of BOTH launches; the forward launch alone is in `forward_only`."""
     from diffusionspatialcontrol_amd import ops
     Bc, H, L, S, d = 2 * n_img, 8, 4096, 77, 40
     C = H * d
@@ -173,7 +226,8 @@ def roofline_region_xattn(dev, n_img):
     pair = graph_launch_time_us(lambda: call())
     fwd = graph_launch_time_us(lambda: call(reuse_stats=True))
     alg_bytes = Bc * (2 * (2 * L * C + 2 * S * C) + 4 * L * S)
-    achieved = alg_bytes / (fwd * 1e-6) / 1e9
+    achieved = alg_bytes / (pair * 1e-6) / 1e9
+    achieved_fwd = alg_bytes / (fwd * 1e-6) / 1e9
     traffic, traffic_note = None, None
     pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pj) and n_img == 1:                              # the PMC passes were taken at Bc = 2
@@ -181,7 +235,8 @@ def roofline_region_xattn(dev, n_img):
             rec = json.load(open(pj))
             if rec.get("kernel_source_sha16") == xattn_source_sha16():
                 traffic = rec.get("xp_fwd_hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 PMC passes of tools/pmc_xattn.py (profiles/pmc_traffic.json), taken on this kernel source"
+                traffic_note = ("HBM bytes of the FORWARD launch: rocprofv3 PMC passes of tools/pmc_xattn.py (profiles/pmc_traffic.json), "
+                                "taken on this kernel source; the statistics launch reads Q once more (+5.4 MB)")
             else:
                 traffic_note = "profiles/pmc_traffic.json was measured on a different version of the kernel source: not reported"
         except Exception:  # noqa: BLE001
@@ -190,16 +245,32 @@ def roofline_region_xattn(dev, n_img):
     # (21 KB per (b, h) at d = 40), uint16 row ids + the distinct rows
     must_move = Bc * (2 * 2 * L * C) + packed.numel() * packed.element_size() \
         + ids.numel() * ids.element_size() + rows.numel() * rows.element_size()
-    return {"kernel": "xp_fwd<3,false> (region cross-attention forward, L=4096 C=320 S=77, Bc=%d)" % Bc,
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-            "frac": round(achieved / 8000.0, 4), "traffic": traffic,
-            "traffic_note": traffic_note,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(fwd, 2),
-            "stats_plus_fwd_us": round(pair, 2),
-            "bytes_the_kernel_must_move": int(must_move),
-            "frac_of_peak_on_bytes_it_must_move": round(must_move / (fwd * 1e-6) / 8e12, 4),
-            "note": "algorithmic bytes = SURVEY.md 8d per-row figure (6.60 MB incl. the dense fp32 table) x Bc rows; the kernel "
-                    "itself reads the table as uint16 row ids + <=32 distinct rows"}
+    r = {"kernel": "xp_stats<3,false> + xp_fwd<3,false,false> (region cross-attention incl. the std pass, L=4096 C=320 S=77, Bc=%d)" % Bc,
+         "bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+         "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+         "traffic_note": traffic_note,
+         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(pair, 2),
+         "what_is_timed": "hot: isolated back-to-back launches of the statistics + forward pair (HIP events around graph-captured launches)",
+         "forward_only": {"avg_launch_us": round(fwd, 2), "achieved": round(achieved_fwd, 1), "frac": round(achieved_fwd / 8000.0, 4)},
+         "bytes_the_kernel_must_move": int(must_move),
+         "frac_of_peak_on_bytes_it_must_move": round(must_move / (fwd * 1e-6) / 8e12, 4),
+         "note": "algorithmic bytes = SURVEY.md 8d per-row figure (6.60 MB incl. the dense fp32 table) x Bc rows, charged ONCE for the op; "
+                 "the kernels read the table as uint16 row ids + <=32 distinct rows"}
+    if n_img == 1:
+        st, fw = in_step_us("xp_stats"), in_step_us("xp_fwd")
+        if st and fw:
+            r["in_step_us"] = {"stats": st, "fwd": fw, "op": round(st + fw, 2),
+                               "frac_op": round(alg_bytes / ((st + fw) * 1e-6) / 8e12, 4),
+                               "frac_forward_only": round(alg_bytes / (fw * 1e-6) / 8e12, 4),
+                               "source": "profiles/in_step_kernels.json: the launches inside the captured UNet step in a rocprofv3 kernel "
+                                         "trace of this command on this kernel source (tools/make_in_step.py)"}
+        else:
+            r["in_step_us"] = None
+        mb = mfma_busy("xp_fwd<3")
+        r["mfma_busy_pct"] = mb["mfma_busy_pct"] if mb else None
+        if mb:
+            r["mfma_busy"] = mb
+    return r
 
 
 def roofline_self_attn(dev, n_img):
@@ -221,7 +292,20 @@ def roofline_self_attn(dev, n_img):
     return {"kernel": "self_attn_fwd (flash self-attention, L=4096 C=320 d=40, Bc=%d; K/V head-major as the pipeline's QKV "
                       "projection writes them)" % Bc, "bound": "mfma",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
-            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2)}
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2),
+            **_in_step_and_busy("self_attn_fwd", "self_attn_fwd<3", flops, n_img)}
+
+
+def _in_step_and_busy(step_key, pmc_prefix, flops, n_img):
+    """the stamped figures of profiles/ for an MFMA-bound kernel of the Bc = 2 workload: its duration inside the captured step
+    and the matrix pipe's busy share from the PMC pass (the metric's "attn MFMA util%")"""
+    if n_img != 1:
+        return {}
+    us = in_step_us(step_key)
+    mb = mfma_busy(pmc_prefix)
+    return {"in_step_us": us, "frac_in_step": round(flops / (us * 1e-6) / 2.5e15, 4) if us else None,
+            "mfma_busy_pct": mb["mfma_busy_pct"] if mb else None,
+            "mfma_busy_pct_of_occupied_simds": mb["mfma_busy_pct_of_occupied_simds"] if mb else None}
 
 
 def roofline_conv3x3(dev, n_img):
@@ -237,7 +321,8 @@ def roofline_conv3x3(dev, n_img):
     tf = flops / (us * 1e-6) / 1e12
     return {"kernel": "conv3x3_kernel<16> (3x3 convolution, 64x64, 320->320, Bc=%d)" % Bc, "bound": "mfma",
             "achieved": round(tf, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4), "traffic": None,
-            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2)}
+            "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 2),
+            **_in_step_and_busy("conv3x3_320_320_64x64", "conv3x3_kernel<16, 3, 0> [320", flops, n_img)}
 
 
 def host_cores():
@@ -254,25 +339,45 @@ def host_cores():
     except Exception:  # noqa: BLE001
         pass
     n = min(n, quota) if quota else n
-    return max(1, min(n, int(os.environ.get("DSC_CPU_THREADS", "16"))))
+    if quota is None and n > 64:
+        # no cgroup quota visible and the whole host in the affinity mask: a 1-GPU box of this pool is granted a 16-CPU share of
+        # its host (more threads than that only contend), so that is what an unlabelled 256-CPU view is taken to mean
+        n = 16
+    if os.environ.get("DSC_CPU_THREADS"):
+        n = int(os.environ["DSC_CPU_THREADS"])
+    return max(1, n)
 
 
-def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sample_steps, total_steps):
-    """oracle on the host cores: `sample_steps` of the `total_steps` denoising steps of the same image, extrapolated"""
+def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sample_steps, total_steps, config1=None):
+    """oracle on the host cores: configs[1] = the `total_steps` denoising steps of the same image, timed
+    in full by default (`--cpu-sample-steps` < total: that many steps, extrapolated and labelled); `config1` = (region tables of
+    ONE mask) -> configs[0], one denoise step of a 64x64 latent with one region mask, timed in full"""
     from oracle import unet_ref
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     sig = sigmas.float().cpu().tolist()
     lat = latents.float().cpu() * math.sqrt(sig[0] ** 2 + 1)
+    c1 = None
+    if config1 is not None:
+        t0 = time.perf_counter()
+        c1_ref = unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), config1, guidance, steps_limit=1)
+        c1 = (time.perf_counter() - t0, c1_ref)
     t0 = time.perf_counter()
     ref = unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), region_state, guidance, steps_limit=sample_steps)
     dt = time.perf_counter() - t0
     per_image = dt / sample_steps * total_steps
-    return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_steps} of {total_steps} denoising steps of one 512x512 image through the fp32 torch oracle "
-                      f"({dt:.1f} s), scaled x{total_steps}/{sample_steps}",
-            "seconds_per_image_extrapolated": round(per_image, 1)}, ref
+    full = sample_steps >= total_steps
+    res = {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": (f"all {total_steps} denoising steps of one 512x512 image (BASELINE configs[1]) through the fp32 torch oracle, "
+                      f"timed in full: {dt:.1f} s" if full else
+                      f"{sample_steps} of {total_steps} denoising steps of one 512x512 image through the fp32 torch oracle "
+                      f"({dt:.1f} s), scaled x{total_steps}/{sample_steps}"),
+           ("seconds_per_image" if full else "seconds_per_image_extrapolated"): round(per_image, 1)}
+    if c1 is not None:
+        res["config1_single_step_s"] = round(c1[0], 2)
+        res["config1"] = "BASELINE configs[0]: one CFG denoise step (UNet forward on 2 rows + DPM++ 2M update) of a 64x64 latent, 1 region mask"
+    return res, ref, (c1[1] if c1 is not None else None)
 
 
 def gpu_sample(pipe, sigmas, text, region_state, latents, guidance, sample_steps):
@@ -465,7 +570,7 @@ def main():
         if n_img == 1 and not a.no_batched_roofline:
             # the same three kernels at the batch of BASELINE configs[2] (8 images per GPU, Bc = 16): what they reach once a
             # launch has enough workgroups to fill the chip - the bench workload above (Bc = 2) is launch-latency bound
-            pick = lambda r: {k_: r[k_] for k_ in ("achieved", "unit", "frac", "avg_launch_us")}    # noqa: E731
+            pick = lambda r: {k_: r[k_] for k_ in ("achieved", "unit", "frac", "avg_launch_us", "forward_only") if k_ in r}    # noqa: E731
             res["roofline_at_8_images"] = {"region_xattn": pick(roofline_region_xattn(dev, 8)),
                                            "self_attn": pick(roofline_self_attn(dev, 8)),
                                            "conv3x3": pick(roofline_conv3x3(dev, 8))}
@@ -474,13 +579,23 @@ def main():
             rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)
             sig = pipe.get_sigmas(a.denoise_steps, {"scheduler": "karras"}).half()
             text = torch.cat([emb[0:1], emb[1:2]]).half()
-            res["cpu_baseline"], ref = cpu_baseline(unet, cfg, sig, text, rs, lat[:1], 7.5, a.cpu_sample_steps, a.denoise_steps)
+            a.cpu_sample_steps = max(1, min(a.cpu_sample_steps, a.denoise_steps))
+            # configs[0]: ONE region mask (the first of the workload's), one step
+            first = next(iter(state))
+            rs1 = encode_region_map(pipe, {first: state[first]}, a.size, a.size, 1, text_ids=ids)
+            res["cpu_baseline"], ref, ref1 = cpu_baseline(unet, cfg, sig, text, rs, lat[:1], 7.5, a.cpu_sample_steps, a.denoise_steps,
+                                                          config1=rs1)
             # the checker's other use: the timed GPU path and the CPU baseline computed the same thing on this sample
             got = gpu_sample(pipe, sig.to(dev), text.to(dev), rs, lat[:1], 7.5, a.cpu_sample_steps).float().cpu()
             err = (got - ref).abs()
             res["cpu_baseline"]["gpu_vs_cpu_on_the_sample"] = {
                 "max_abs_err": round(err.max().item(), 5), "mean_abs_err": round(err.mean().item(), 6),
-                "ref_max_abs": round(ref.abs().max().item(), 4), "note": "latents after the sampled steps: fp16 HIP path vs fp32 oracle"}
+                "ref_max_abs": round(ref.abs().max().item(), 4),
+                "note": f"latents after {a.cpu_sample_steps} of {a.denoise_steps} steps: fp16 HIP path vs fp32 oracle"}
+            got1 = gpu_sample(pipe, sig.to(dev), text.to(dev), rs1, lat[:1], 7.5, 1).float().cpu()
+            err1 = (got1 - ref1).abs()
+            res["cpu_baseline"]["config1_gpu_vs_cpu"] = {"max_abs_err": round(err1.max().item(), 5), "mean_abs_err": round(err1.mean().item(), 6),
+                                                         "ref_max_abs": round(ref1.abs().max().item(), 4)}
     # self-describing multi-GPU lines: what each rank ran on
     me = f"{torch.cuda.get_device_name(dev)} (cuda:{local} of {torch.cuda.device_count()} visible)"
     if dist:
@@ -490,6 +605,7 @@ def main():
         names = [me]
     if res is not None:
         res["config"]["devices"] = names
+    ranks_equal = True
     if dist and not a.decode:
         # per-image equality across ranks: every rank hashes the final latents of its images (one generation
         # at a time, latency rules); rank 0 generates EVERY rank's images itself and compares - the same bits are expected since
@@ -500,9 +616,10 @@ def main():
         hashes = [None] * world
         td.all_gather_object(hashes, mine)
         if res is not None:
-            own = [hashlib.sha256(generate(0, start_latents(shard_image_indices(n_img * world, r_, world))).float().cpu().numpy().tobytes()).hexdigest()
+            regen = [hashlib.sha256(generate(0, start_latents(shard_image_indices(n_img * world, r_, world))).float().cpu().numpy().tobytes()).hexdigest()
                    for r_ in range(world)]
-            res["config"]["ranks_equal_single_process"] = bool(own == hashes)
+            res["config"]["ranks_equal_single_process"] = ranks_equal = bool(regen == hashes)
+            res["config"]["dist_backend"] = backend if backend == "nccl" else f"{backend} (NOT RCCL: a rehearsal, not a multi-GPU measurement)"
         td.barrier()
     if nfl > 1:
         # the launch rules for generations that SHARE the chip (include/dsc_hip.h, dsc_set_tuning_profile): the legs above ran
@@ -597,6 +714,10 @@ def main():
     if dist:
         td.barrier()
         td.destroy_process_group()
+    if not ranks_equal:
+        # README / INTEGRATION claim the same bits on every rank: a run that shows otherwise must not look like rc 0
+        print("bench.py: a rank's final latents differ from rank 0's regeneration of the same images", file=sys.stderr, flush=True)
+        raise SystemExit(4)
 
 
 if __name__ == "__main__":

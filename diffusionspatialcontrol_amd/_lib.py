@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dsc_set_tuning_profile": (ctypes.c_int, [ctypes.c_int]),
     "dsc_get_tuning_profile": (ctypes.c_int, []),
     "dsc_linear_lt_stats": (None, [_vp]),
+    "dsc_has_library_gemm": (ctypes.c_int, []),
     "dsc_add_bias_residual": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_linear_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                        [ctypes.c_int, ctypes.c_int, _vp]),
@@ -130,6 +131,9 @@ def load_library():
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    if os.environ.get("DSC_LIBRARY_GEMM", "0") != "0" and not lib.dsc_has_library_gemm():
+        raise DscLibraryError(f"DSC_LIBRARY_GEMM=1 asks for the hipBLASLt routing, but {path} was built without it: rebuild with "
+                              "`DSC_WITH_HIPBLASLT=1 python -m diffusionspatialcontrol_amd.build --force`")
     if os.environ.get("DSC_SA_VARIANT"):                       # A/B switch: force one tiling of the flash self-attention kernel
         lib.dsc_debug_set_self_attn_variant(int(os.environ["DSC_SA_VARIANT"]))
     if os.environ.get("DSC_TUNING_PROFILE"):                   # latency (default) / throughput: dsc_set_tuning_profile at load time

@@ -11,6 +11,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdsc_hip.so")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17"]
+# the hipBLASLt fallback (csrc/linear_lt.hip) is a BUILD option, off by default: the default .so neither contains nor links the
+# library.  DSC_WITH_HIPBLASLT=1 in the environment of the build compiles it in (A/B runs against the package's own GEMMs).
+WITH_HIPBLASLT = os.environ.get("DSC_WITH_HIPBLASLT", "0") not in ("", "0")
+if WITH_HIPBLASLT:
+    FLAGS = FLAGS + ["-DDSC_WITH_HIPBLASLT=1"]
 
 
 STAMP = os.path.join(HERE, "_obj", "sources.sha256")
@@ -54,7 +59,7 @@ def build(force=False, verbose=True):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-lhipblaslt"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + (["-lhipblaslt"] if WITH_HIPBLASLT else [])
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -596,7 +596,8 @@ extern "C" int dsc_conv3x3_nhwc_f16(const void* x, const void* w, const void* bi
 extern "C" int dsc_conv3x3_gn_rows(int B, int H, int W, int Cin, int Cout, int groups, int resample) {
     ConvParams p{};
     const int Hc = H, Wc = W;
-    if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cout % BN != 0 || Cout % groups != 0 || Cout / groups > 64) return 0;
+    // 2 <= channels per group <= 64: gn_tile_partials writes at most 32 group slots per 64-channel tile (gn_partials.h)
+    if (B <= 0 || H <= 0 || W <= 0 || groups <= 0 || Cout % BN != 0 || Cout % groups != 0 || Cout / groups > 64 || Cout / groups < 2) return 0;
     if (resample == DSC_CONV_STRIDE2 || resample == DSC_CONV_STRIDE2_PAD_BR) return 0;   // (the kept pixels are a quarter of a tile's)
     if (plan(B, Hc, Wc, Cin, Cout, 0, &p) != 16 || p.splits != 1 || p.bpi > 128) return 0;
     return p.bpi;

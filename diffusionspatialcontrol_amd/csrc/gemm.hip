@@ -642,7 +642,7 @@ int gemm_tile_rows(int64_t M, int N, bool geglu) {
 // partial rows per image of dsc_linear_gn_f16 (row tiles per image), 0 when the shape is not covered
 extern "C" int dsc_linear_gn_rows(int64_t M, int N, int K, int rows_per_image, int groups) {
     if (M <= 0 || N <= 0 || K <= 0 || rows_per_image <= 0 || groups <= 0 || K % BK != 0 || N % BN != 0 || N % groups != 0 ||
-        N / groups > 64 || M % rows_per_image != 0)
+        N / groups > 64 || N / groups < 2 || M % rows_per_image != 0)     // (>= 2 channels per group: 32 group slots per tile, gn_partials.h)
         return 0;
     const int bm = gemm_tile_rows(M, N, false);
     if (rows_per_image % bm != 0 || rows_per_image / bm > 128) return 0;

@@ -9,14 +9,47 @@
 // made on top of it: which of the heuristic's candidate algorithms runs - the first call of a shape times up to
 // DSC_LT_TUNE (default 16) of them on the caller's operands, in the cache state of a UNet step (tune_plan), and keeps the
 // fastest (DSC_LT_TUNE=1: the heuristic's first choice, as torch takes it).
+//
+// BUILD FLAG (round 4): the default libdsc_hip.so does NOT contain or link hipBLASLt - no linear of the step has gone to the
+// library since round 3 (every one runs on gemm_tn_f16 / split-K), so the default build keeps only the entry points, which then
+// decline (DSC_ERR_UNSUPPORTED -> the caller runs the hand-written GEMM).  `DSC_WITH_HIPBLASLT=1 python -m
+// diffusionspatialcontrol_amd.build` compiles the library path back in (-DDSC_WITH_HIPBLASLT=1, -lhipblaslt) for A/B runs
+// (DSC_LIBRARY_GEMM=1 then routes to it); dsc_has_library_gemm() tells which build is loaded.
 #include <hip/hip_runtime.h>
-#include <hipblaslt/hipblaslt.h>
 #include <stdint.h>
+#include "dsc_hip.h"
+
+#ifndef DSC_WITH_HIPBLASLT
+#define DSC_WITH_HIPBLASLT 0
+#endif
+
+extern "C" int dsc_has_library_gemm(void) { return DSC_WITH_HIPBLASLT; }
+
+#if !DSC_WITH_HIPBLASLT
+
+namespace { thread_local int t_ws_slot_stub = 0; }
+
+extern "C" void dsc_linear_lt_stats(long long out[3]) { out[0] = out[1] = out[2] = 0; }
+
+extern "C" int dsc_set_workspace_slot(int slot) {
+    if (slot < 0 || slot >= 4) return DSC_ERR_BAD_ARG;
+    t_ws_slot_stub = slot;
+    return DSC_OK;
+}
+
+extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void*, const void*, void* out, int64_t M, int N, int K, int64_t,
+                                 int64_t, int64_t, int, void*) {
+    if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
+    return DSC_ERR_UNSUPPORTED;                    // built without the library: the caller's own GEMM takes the shape
+}
+
+#else  // DSC_WITH_HIPBLASLT
+
+#include <hipblaslt/hipblaslt.h>
 #include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <tuple>
-#include "dsc_hip.h"
 
 extern int g_dsc_tuning_profile;     // c_api.hip
 
@@ -226,3 +259,5 @@ extern "C" int dsc_linear_lt_f16(const void* x, const void* w, const void* bias,
                                                workspace_for(), ws_bytes(), hs);
     return st == HIPBLAS_STATUS_SUCCESS ? DSC_OK : DSC_ERR_LAUNCH;
 }
+
+#endif  // DSC_WITH_HIPBLASLT

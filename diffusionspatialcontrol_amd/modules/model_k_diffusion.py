@@ -1134,22 +1134,27 @@ class StableDiffusionPipeline:
 
     @staticmethod
     def _weight_func_key(weight_func):
-        """"default" for anything that behaves as `w * sigma * qk.std()`; otherwise by VALUE where the callable allows it -
-        (code object, closure cell contents, defaults), so that app.py's fresh lambda per request (app.py:1004) re-uses the
-        captured step instead of paying two warm-up steps and a capture under the capture lock per request - and by object
-        identity when a captured value is not hashable (two closures of one code object may capture different values)."""
+        """"default" for anything that behaves as `w * sigma * qk.std()`; otherwise by VALUE where that is safe - (code object,
+        closure cell contents, defaults) when every captured value is an immutable scalar (int / float / bool / str / None or a
+        tuple of those), so that app.py's fresh lambda per request (app.py:1004) re-uses the captured step instead of paying two
+        warm-up steps and a capture under the capture lock per request - and by object identity otherwise: a captured MUTABLE
+        object hashes by identity, two closures over it would share one captured step whose baked-in scalars go stale when the
+        object changes, and the key would keep the object alive as long as the graph cache."""
         if weight_func is None or weight_func_is_default(weight_func):
             return "default"
+
+        def immutable(v):
+            return v is None or type(v) in (int, float, bool, str) or (type(v) is tuple and all(immutable(e) for e in v))
+
         code = getattr(weight_func, "__code__", None)
         if code is not None:
             try:
                 cells = tuple(c.cell_contents for c in (getattr(weight_func, "__closure__", None) or ()))
-                key = ("wf", code, cells, getattr(weight_func, "__defaults__", None),
-                       tuple(sorted((getattr(weight_func, "__kwdefaults__", None) or {}).items())))
-                hash(key)
-                if not any(torch.is_tensor(v) for v in cells):      # tensors hash by identity and compare elementwise
-                    return key
-            except (TypeError, ValueError):                          # unhashable capture / empty cell
+                defaults = getattr(weight_func, "__defaults__", None) or ()
+                kwdefaults = tuple(sorted((getattr(weight_func, "__kwdefaults__", None) or {}).items()))
+                if all(immutable(v) for v in cells) and all(immutable(v) for v in defaults) and all(immutable(v) for _, v in kwdefaults):
+                    return ("wf", code, cells, defaults, kwdefaults)
+            except ValueError:                                       # empty cell
                 pass
         return id(weight_func)
 

@@ -269,9 +269,9 @@ class UNetConfig:
 
 def _derived(module, key, deps, build):
     """A tensor derived from parameters (concatenated / summed weights), cached on the module and rebuilt when any
-    source parameter object or its in-place version changes.  Derived tensors are not parameters: state_dict keys
-    stay the diffusers ones."""
-    sig = tuple((id(t), t._version) for t in deps)
+    source parameter object or its in-place version changes (non-tensor entries of `deps`, e.g. a token count, compare by
+    value).  Derived tensors are not parameters: state_dict keys stay the diffusers ones."""
+    sig = tuple((id(t), t._version) if torch.is_tensor(t) else t for t in deps)
     hit = module.__dict__.get("_derived_" + key)
     if hit is None or hit[0] != sig:
         with torch.no_grad():

@@ -83,21 +83,27 @@ class VaeAttention(nn.Module):
         """one image: q, k [L, c], vt = v^T [c, L] -> softmax(q k^T / sqrt(c)) v  [L, c].  The scores are materialised once
         in fp16 (dsc_linear_f16: 'weight' = the keys), normalised in fp32 (dsc_softmax_rows_f16) and contracted with v^T as
         the second GEMM's [N, K] operand - a 512-channel head does not fit the flash kernel's registers."""
-        scores = ops.linear(q, k, prefer_kernel=True)                                    # [L, L] = q . k^T
-        probs = ops.softmax_rows(scores, scale=q.shape[-1] ** -0.5, out=scores)         # in place: one 2 L^2-byte buffer
+        # q arrives pre-multiplied by c^-1/2 (forward: the scale is folded into the to_q projection), so the fp16 scores are the
+        # SCALED logits - the headroom the replaced SDPA path had (unscaled q.k^T at c = 512 is 22.6x larger and could reach inf)
+        scores = ops.linear(q, k, prefer_kernel=True)                                    # [L, L] = (q c^-1/2) . k^T
+        probs = ops.softmax_rows(scores, scale=1.0, out=scores)                          # in place: one 2 L^2-byte buffer
         return ops.linear(probs, vt, prefer_kernel=True)                                 # [L, c] = p . v
 
     def forward(self, x):
         b, c, h, w = x.shape
         t = _tokens(self.group_norm(x))
         if self._hip_covers(t):
-            q = ops.linear(t, self.to_q.weight, self.to_q.bias, prefer_kernel=True)
+            from .u_net_condition_modify import _derived
+            wq, bq = _derived(self, "to_q_scaled", (self.to_q.weight, self.to_q.bias),
+                              lambda: ((self.to_q.weight.detach().float() * c ** -0.5).to(self.to_q.weight.dtype).contiguous(),
+                                       (self.to_q.bias.detach().float() * c ** -0.5).to(self.to_q.bias.dtype).contiguous()))
+            q = ops.linear(t, wq, bq, prefer_kernel=True)                                # = to_q(t) / sqrt(c)
             k = ops.linear(t, self.to_k.weight, self.to_k.bias, prefer_kernel=True)
             L = h * w
             # v^T [c, L] straight from a GEMM with the roles swapped (x = W_v, 'weight' = the tokens); its bias is a ROW
             # constant there, so it rides as the GEMM's residual operand (a [c, L] expansion of b_v, cached per L)
-            from .u_net_condition_modify import _derived
-            bcol = _derived(self, f"vbias_{L}", (self.to_v.bias,),
+            # (ONE cached expansion: a new image size replaces the previous one, the cache does not grow with the sizes seen)
+            bcol = _derived(self, "vbias", (self.to_v.bias, L),
                             lambda: self.to_v.bias.detach()[:, None].expand(c, L).contiguous())
             outs = []
             for i in range(b):

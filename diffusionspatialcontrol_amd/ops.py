@@ -259,6 +259,7 @@ def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp1
 def self_attention(q, k, v, scale=None, out=None):
     """softmax(q.k^T * scale) . v for q [B, L, H, d], k/v [B, S, H, d] (strided views allowed) -> [B, L, H, d]
     contiguous (dsc_self_attn_fwd: flash attention, scores never materialised)."""
+    _drop_gn_partials(out)
     _require_gpu(q, k, v)
     if q.dtype != torch.float16:
         raise TypeError("self_attention: fp16 only")
@@ -324,6 +325,7 @@ def groupnorm_silu_nhwc(x, groups, weight, bias, eps, act, add=None):
     return y
 
 
+GN_CHECK = os.environ.get("DSC_GN_CHECK", "0") != "0"      # debug: verify a producer's partial sums against the tensor before use
 USE_GN_FUSE = os.environ.get("DSC_GN_FUSE", "1") != "0"   # GroupNorm statistics from the producing convolution / GEMM epilogue (gn_partials.h)
 
 
@@ -338,10 +340,22 @@ class GnPartials:
 
 
 def attach_gn_partials(t, part):
-    """hand a producer's partial sums on with the tensor OBJECT `t` (a view of the producer's output is fine: same bytes)"""
+    """hand a producer's partial sums on with the tensor OBJECT `t` (a view of the producer's output is fine: same bytes).
+
+    CONTRACT: the sums are invalidated through torch's `_version` counter only, and this package's own kernels write through raw
+    pointers (ctypes), which does not bump it - so NO dsc_* call may write in place into (or take as `out=`) a tensor that carries
+    partials.  The ops of this module that accept `out=` or write in place drop the attribute from their destination
+    (`_drop_gn_partials`); `DSC_GN_CHECK=1` makes `groupnorm_apply_nhwc` recompute the statistics from the tensor and compare."""
     if part is not None:
         part.version = t._version
         t._dsc_gn = part
+    return t
+
+
+def _drop_gn_partials(t):
+    """a dsc_* kernel is about to write into `t` through its raw pointer: sums a producer attached to it no longer describe it"""
+    if t is not None and getattr(t, "_dsc_gn", None) is not None:
+        t._dsc_gn = None
     return t
 
 
@@ -360,6 +374,14 @@ def groupnorm_apply_nhwc(x, part, groups, weight, bias, eps, act):
     B, C, h, w = x.shape
     if part.groups != groups or part.C != C or part.B != B or part.hw != h * w or not x.is_contiguous(memory_format=torch.channels_last):
         raise ValueError("groupnorm_apply_nhwc: the partial sums do not belong to this tensor / grouping")
+    if GN_CHECK:                               # debug: the producer's sums against statistics recomputed from the tensor itself
+        cpg = C // groups
+        pv = part.buf.view(B, part.rows, groups, 2, 2).double()
+        straddles = torch.tensor([(g * cpg) // 64 != ((g + 1) * cpg - 1) // 64 for g in range(groups)], device=x.device)
+        sums = pv[:, :, :, 0, 0].sum(1) + torch.where(straddles, pv[:, :, :, 1, 0].sum(1), torch.zeros((), dtype=pv.dtype, device=x.device))
+        ref = x.double().reshape(B, groups, C // groups, h * w).sum(dim=(2, 3))
+        if not torch.allclose(sums, ref, rtol=1e-3, atol=1e-2 * (C // groups) * h * w ** 0.5):
+            raise RuntimeError("groupnorm_apply_nhwc: stale GroupNorm partial sums (the tensor was written after its producer)")
     y = torch.empty_like(x, memory_format=torch.channels_last)
     rc = _lib.load_library().dsc_groupnorm_apply_nhwc(_p(x), _p(y), _p(weight), _p(bias), _p(part.buf), part.rows, B, C, h * w,
                                                       groups, float(eps), 1 if act else 0, 0, _stream_ptr(x))
@@ -857,6 +879,7 @@ def add_layernorm(x, a, weight, bias, eps=1e-5):
 def softmax_rows(scores, scale=1.0, out=None):
     """softmax(scale * scores, dim=-1) of an fp16 [rows, n] matrix (unit inner stride, 16-byte aligned rows) in fp32 arithmetic
     (dsc_softmax_rows_f16) - the middle step of the VAE's 512-channel attention head between its two GEMMs."""
+    _drop_gn_partials(out)
     _require_gpu(scores)
     if scores.dtype != torch.float16 or scores.dim() != 2 or scores.stride(1) != 1:
         raise TypeError("softmax_rows: a 2-D fp16 matrix with unit inner stride")

@@ -346,6 +346,10 @@ int dsc_conv3x3_fewcin_f16(const void* x_nchw, const void* w_t, const void* bias
  */
 int dsc_linear_lt_f16(const void* x, const void* w, const void* bias, const void* residual, void* out,
                       int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int dtype, void* stream);
+/* 1 when this build of the library contains the hipBLASLt path above (built with DSC_WITH_HIPBLASLT=1), 0 for the default
+ * build, which neither contains nor links hipBLASLt: dsc_linear_lt_f16 then returns DSC_ERR_UNSUPPORTED for every shape and
+ * the caller's own GEMM (dsc_linear_f16 / dsc_linear_splitk_f16) runs it - what the pipeline does by default since round 3. */
+int dsc_has_library_gemm(void);
 /* Generation slot of the calling host thread (0..3, default 0): which of the library-GEMM workspaces dsc_linear_lt_f16 hands
  * to hipBLASLt (its stream-K kernels keep partial tiles there).  A pipeline that keeps two generations in flight on two
  * streams drives each from its own thread / slot, so that neither the eager GEMMs nor the ones baked into the two captured

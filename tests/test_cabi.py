@@ -129,3 +129,31 @@ def test_tuning_profile_entry_points(lib):
     assert lib.dsc_set_tuning_profile(1) == 0 and lib.dsc_get_tuning_profile() == 1
     assert lib.dsc_set_tuning_profile(2) == -1 and lib.dsc_set_tuning_profile(-1) == -1 and lib.dsc_get_tuning_profile() == 1
     assert lib.dsc_set_tuning_profile(0) == 0 and lib.dsc_get_tuning_profile() == 0
+
+
+def test_groupnorm_partial_sums_need_two_channels_per_group(lib):
+    """round-3 advisor: gn_tile_partials writes at most 32 group slots per 64-channel tile, so a grouping with ONE channel per
+    group (C == groups == 64) would leave half the slots unwritten - both producers must decline it (0 rows -> the caller
+    runs the two-launch GroupNorm), while 2..64 channels per group are covered.  Host-side planning only: no GPU."""
+    assert lib.dsc_linear_gn_rows(8192, 64, 320, 4096, 64) == 0
+    assert lib.dsc_linear_gn_rows(8192, 64, 320, 4096, 32) > 0
+    assert lib.dsc_linear_gn_rows(8192, 320, 320, 4096, 32) > 0
+    assert lib.dsc_conv3x3_gn_rows(2, 64, 64, 64, 64, 64, 0) == 0
+    assert lib.dsc_conv3x3_gn_rows(2, 64, 64, 64, 64, 32, 0) > 0
+    assert lib.dsc_conv3x3_gn_rows(2, 64, 64, 320, 320, 32, 0) > 0
+
+
+def test_default_build_does_not_link_hipblaslt(lib):
+    """the hipBLASLt fallback is a build option (DSC_WITH_HIPBLASLT=1): the default library neither links it nor claims it, and
+    its entry point declines instead of launching"""
+    if dsc_build.WITH_HIPBLASLT:
+        pytest.skip("this tree was built with DSC_WITH_HIPBLASLT=1")
+    assert lib.dsc_has_library_gemm() == 0
+    needed = subprocess.run(["readelf", "-d", dsc.lib_path()], capture_output=True, text=True).stdout
+    assert "hipblaslt" not in needed
+    st3 = (ctypes.c_longlong * 3)(7, 7, 7)
+    lib.dsc_linear_lt_stats(st3)
+    assert list(st3) == [0, 0, 0]
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.dsc_linear_lt_f16(p, p, None, None, p, 8, 8, 8, 8, 8, 8, 0, None) != 0

@@ -124,6 +124,35 @@ def test_sd15_three_step_loop_full_size_vs_oracle(sd15):
     assert err.mean().item() < 3e-4 * scale
 
 
+def test_config1_single_step_one_mask(sd15):
+    """BASELINE configs[0] as written: ONE denoise step of a 64x64 latent with ONE region mask.  The 1-mask table comes from
+    `encode_region_map` (reference encode_region_map_function.py:21-77: one phrase -> token columns 2, 3; every level's table
+    has two distinct rows), the step is one CFG `model_fn` call (model_k_diffusion.py:1091-1171, CompVisDenoiser.forward
+    external_k_diffusion.py:109-114) + the first DPM++ 2M update to sigma_1; fused HIP loop vs the fp32 oracle loop.
+    Bounds: the per-forward tolerance of this file carried through one update - 2e-3 of the latent range (max), 3e-4 (mean).
+    Also checked: the denoised estimate of that single model call (a sampler-free view of the same step: steps_limit = 1 on a
+    [sigma_0, 0] schedule returns the CFG-combined denoised itself)."""
+    emb, ids, state, _ = _inputs(512, 1)
+    assert len(state) == 1
+    rs = _region_tables(sd15.pipe, state, 512, ids)
+    assert sorted(rs) == [64, 256, 1024, 4096]
+    for L, w in rs.items():                                  # one mask: background row + region row (columns 2, 3 carry 0.5)
+        assert w.shape == (2, L, 77) and len(torch.unique(w[1], dim=0)) == 2
+        assert torch.count_nonzero(w[..., 4:]).item() == 0 and w[1, :, 2:4].max().item() == 0.5
+    sig = sd15.pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
+    lat = _latent(0)[None]
+    text = torch.cat([emb[0:1], emb[1:2]])
+    for name, schedule in (("one DPM++ 2M step", sig), ("denoised of one model call", [sig[0], 0.0])):
+        ref = _oracle_loop(sd15, lat.half(), schedule, text.half(), rs, 1)
+        got = _fused(sd15, lat, schedule, text, rs, 1)
+        scale = ref.abs().max().item()
+        err = (got - ref).abs()
+        print(f"configs[0] {name}: max {err.max().item():.3e} mean {err.mean().item():.3e} range {scale:.2f}")
+        assert torch.isfinite(got).all()
+        assert err.max().item() < 2e-3 * scale, (name, err.max().item(), scale)
+        assert err.mean().item() < 3e-4 * scale, (name, err.mean().item(), scale)
+
+
 def test_config3_eight_images_four_masks(sd15):
     """BASELINE configs[2] on one GPU: 8 images per generation, 4 region masks (Bc = 16, n_std_groups = 8)."""
     from diffusionspatialcontrol_amd.modules.attention_modify import AttnProcessor2_0

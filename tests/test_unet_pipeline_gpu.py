@@ -491,8 +491,26 @@ def test_conv3x3_unsupported(ops):
 @pytest.mark.parametrize("M,N,K", [(512, 1280, 1280), (512, 1280, 5120), (128, 1280, 1280), (8192, 320, 1280), (2048, 640, 2560),
                                    (77, 320, 768)])
 def test_linear_library_bias_residual(ops, M, N, K):
-    """dsc_linear_lt_f16: the hipBLASLt GEMM with bias epilogue + residual as beta*C, one launch; also under graph capture"""
+    """dsc_linear_lt_f16: the hipBLASLt GEMM with bias epilogue + residual as beta*C, one launch; also under graph capture.
+    The default build does not contain the library (DSC_WITH_HIPBLASLT=1 at build time compiles it in): there the entry point
+    must DECLINE and ops.linear must still give the right numbers on the package's own GEMMs."""
     from diffusionspatialcontrol_amd import _lib
+    if not _lib.load_library().dsc_has_library_gemm():
+        g = torch.Generator().manual_seed(M + N + K + 1)
+        x = torch.randn(M, K, generator=g).half().cuda()
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
+        b = (torch.randn(N, generator=g) * 0.2).half().cuda()
+        r = torch.randn(M, N, generator=g).half().cuda()
+        out = torch.empty(M, N, dtype=torch.half, device="cuda")
+        import ctypes
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())                                 # noqa: E731
+        rc = _lib.load_library().dsc_linear_lt_f16(vp(x), vp(w), vp(b), vp(r), vp(out), M, N, K, K, N, N, 0,
+                                                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0                                                               # declined, no launch
+        ref = x.float() @ w.float().t() + b.float() + r.float()
+        y = ops.linear(x, w, b, residual=r)
+        assert torch.all((y.float() - ref).abs() <= 2e-3 * ref.abs() + 4e-3)
+        return
     g = torch.Generator().manual_seed(M + N + K + 1)
     x = torch.randn(M, K, generator=g).half().cuda()
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).half().cuda()
@@ -1575,6 +1593,8 @@ def test_library_gemms_on_two_streams_finish_and_need_no_workspace(library_routi
     import ctypes
     import threading
     from diffusionspatialcontrol_amd import _lib
+    if not _lib.load_library().dsc_has_library_gemm():
+        pytest.skip("default build: hipBLASLt is not compiled in (DSC_WITH_HIPBLASLT=1 at build time restores the fallback)")
     ops = library_routing
     shapes = [(512, 1280, 5120), (2048, 640, 2560), (8192, 320, 1280), (512, 1280, 2560), (512, 1280, 1920), (128, 1280, 1280),
               (128, 1280, 5120), (128, 1280, 2560), (2048, 640, 1920), (2048, 640, 1280), (8192, 320, 960)]
