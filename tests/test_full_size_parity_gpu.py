@@ -129,9 +129,13 @@ def test_config1_single_step_one_mask(sd15):
     `encode_region_map` (reference encode_region_map_function.py:21-77: one phrase -> token columns 2, 3; every level's table
     has two distinct rows), the step is one CFG `model_fn` call (model_k_diffusion.py:1091-1171, CompVisDenoiser.forward
     external_k_diffusion.py:109-114) + the first DPM++ 2M update to sigma_1; fused HIP loop vs the fp32 oracle loop.
-    Bounds: the per-forward tolerance of this file carried through one update - 2e-3 of the latent range (max), 3e-4 (mean).
+    Bounds: the per-forward tolerance of this file carried through one update - 2e-3 of the latent range (max), 3e-4 (mean);
+    observed 5e-4 / 8e-5.
     Also checked: the denoised estimate of that single model call (a sampler-free view of the same step: steps_limit = 1 on a
-    [sigma_0, 0] schedule returns the CFG-combined denoised itself)."""
+    [sigma_0, 0] schedule returns the CFG-combined denoised itself).  Its bound is wider BY CONSTRUCTION: denoised = x - sigma_0 *
+    (-6.5 eps_u + 7.5 eps_c) multiplies the two forwards' errors by sigma_0 = 14.6 and by ~10 (the CFG combination), so a forward at
+    its usual 1.1e-3 of the eps range shows as 3.2e-3 of the latent range here (observed) - bound 6e-3 max, 1e-3 mean; the first
+    DPM++ 2M update then weights it with 1 - sigma_1 / sigma_0 = 0.16."""
     emb, ids, state, _ = _inputs(512, 1)
     assert len(state) == 1
     rs = _region_tables(sd15.pipe, state, 512, ids)
@@ -142,15 +146,15 @@ def test_config1_single_step_one_mask(sd15):
     sig = sd15.pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
     lat = _latent(0)[None]
     text = torch.cat([emb[0:1], emb[1:2]])
-    for name, schedule in (("one DPM++ 2M step", sig), ("denoised of one model call", [sig[0], 0.0])):
+    for name, schedule, tol_max, tol_mean in (("one DPM++ 2M step", sig, 2e-3, 3e-4), ("denoised of one model call", [sig[0], 0.0], 6e-3, 1e-3)):
         ref = _oracle_loop(sd15, lat.half(), schedule, text.half(), rs, 1)
         got = _fused(sd15, lat, schedule, text, rs, 1)
         scale = ref.abs().max().item()
         err = (got - ref).abs()
         print(f"configs[0] {name}: max {err.max().item():.3e} mean {err.mean().item():.3e} range {scale:.2f}")
         assert torch.isfinite(got).all()
-        assert err.max().item() < 2e-3 * scale, (name, err.max().item(), scale)
-        assert err.mean().item() < 3e-4 * scale, (name, err.mean().item(), scale)
+        assert err.max().item() < tol_max * scale, (name, err.max().item(), scale)
+        assert err.mean().item() < tol_mean * scale, (name, err.mean().item(), scale)
 
 
 def test_config3_eight_images_four_masks(sd15):
