@@ -83,6 +83,10 @@ def parse():
     ap.add_argument("--decode", action="store_true",
                     help="also run the VAE decoder (SURVEY.md 8f rank 1) inside the timed region; off by default so the "
                          "headline stays the denoising path of BASELINE.json")
+    ap.add_argument("--no-coalesced", action="store_true",
+                    help="skip the coalesced_requests leg (k concurrent batch-1 requests in one captured step, txt2img_coalesced)")
+    ap.add_argument("--coalesce-sweep", default="2x1,4x1,8x1,2x2,4x2,8x2",
+                    help="the (requests per captured step) x (generations in flight) points of the coalesced_requests leg")
     ap.add_argument("--cpu-sample-steps", type=int, default=25,
                     help="denoising steps of the cpu_baseline leg (oracle on the host cores): all 25 by default (BASELINE.md section 2: "
                          "configs[1] timed in full, about two minutes on 16 cores); fewer -> extrapolated and labelled as such")
@@ -697,6 +701,66 @@ def main():
                                   "per_rank_images_per_s": rates_fl, "max_over_ranks_s": round(dt, 4),
                                   "outputs_finite": finite and all(bool(torch.isfinite(o).all().item()) for o in slot_outs),
                                   "workload": res["config"]["workload"].replace("1 generation(s) in flight", f"{nfl} generation(s) in flight")})
+    if res is not None and world == 1 and n_img == 1 and not a.no_coalesced and not a.decode and not a.no_graph:
+        # Serving mode (not the headline, which stays BASELINE configs[1]: batch-1 generations): k CONCURRENT batch-1 requests of
+        # the same workload - own start latent each, configs[1]'s prompt and masks - denoised by ONE captured step per sigma
+        # (txt2img_coalesced: per-request std groups and tables, every kernel on k times the rows), f such generations in flight
+        ops.set_tuning_profile("throughput" if a.tuning_profile == "auto" else a.tuning_profile)
+
+        def coalesced(k, f):
+            reqs = [{"prompt_embeds": emb[1:2], "negative_prompt_embeds": emb[0:1], "text_input_ids": ids, "region_map_state": state,
+                     "latents": start_latents([i])} for i in range(k)]
+            gen = lambda s_i: pipe.txt2img_coalesced(reqs, height=a.size, width=a.size, num_inference_steps=a.denoise_steps,   # noqa: E731
+                                                     guidance_scale=7.5, sampler_opt={"scheduler": "karras"}, slot=s_i)
+            sts = [torch.cuda.Stream() for _ in range(f)]
+            for s_i, st_ in enumerate(sts):                   # capture + warm-up per slot, untimed
+                with torch.cuda.stream(st_):
+                    gen(s_i)
+                torch.cuda.synchronize()
+            n_gen = max(2 * f, (16 + k - 1) // k)
+            todo_, lock_ = iter(range(n_gen)), threading.Lock()
+            errs_ = []
+
+            def drive_(s_i):
+                try:
+                    torch.cuda.set_device(dev)
+                    with torch.cuda.stream(sts[s_i]):
+                        while True:
+                            with lock_:
+                                if next(todo_, None) is None:
+                                    break
+                            gen(s_i)
+                except BaseException as e:                  # noqa: BLE001
+                    errs_.append(e)
+
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            ths = [threading.Thread(target=drive_, args=(i,), daemon=True) for i in range(f)]
+            for t_ in ths:
+                t_.start()
+            for t_ in ths:
+                t_.join(timeout=a.stall_seconds)
+            if any(t_.is_alive() for t_ in ths):
+                raise RuntimeError(f"coalesced leg k={k} f={f} stalled")
+            torch.cuda.synchronize()
+            dt_ = time.perf_counter() - t0_
+            if errs_:
+                raise errs_[0]
+            return {"requests_per_step": k, "generations_in_flight": f, "images_per_s": round(n_gen * k / dt_, 3),
+                    "ms_per_image_latency": round(dt_ / n_gen * f * 1e3, 1), "generations_timed": n_gen}
+
+        try:
+            sweep = [coalesced(*map(int, pt.split("x"))) for pt in a.coalesce_sweep.split(",") if pt]
+            best = max(sweep, key=lambda r_: r_["images_per_s"])
+            res["coalesced_requests"] = {
+                "best": best, "sweep": sweep,
+                "vs_headline": round(best["images_per_s"] / res["value"], 3),
+                "note": "serving mode, NOT the headline: k concurrent batch-1 requests (own latent each; this workload's prompt and "
+                        "2 masks) share one captured UNet step per sigma (StableDiffusionPipeline.txt2img_coalesced: per-request std "
+                        "groups, rows [u_0..u_k-1, c_0..c_k-1]); ms_per_image_latency = wall time of a request from entering a "
+                        "batch to its latents (every request of a batch finishes with the batch)"}
+        except Exception as e:  # noqa: BLE001 - the headline line must survive a failure of this extra leg
+            res["coalesced_requests"] = {"error": repr(e)}
     if res is not None:
         try:
             import ctypes

@@ -532,6 +532,69 @@ class StableDiffusionPipeline:
             return latents_process
         return [self.latent_to_image(latents, output_type)]
 
+    def txt2img_coalesced(self, requests, height: int = 512, width: int = 512, num_inference_steps: int = 50,
+                          guidance_scale: float = 7.5, sampler_opt=None, output_type: Optional[str] = "latent",
+                          weight_func=lambda w, sigma, qk: w * sigma * qk.std(), cross_attention_kwargs=None,
+                          start_time=-1, timeout=180, slot: int = 0):
+        """k CONCURRENT batch-1 requests - each with its own prompt rows, region masks and start latent - denoised together by ONE
+        captured UNet step per sigma (serving mode; the reference serialises requests: Gradio `queue()`, app.py:3063, one latent
+        per `txt2img` call).  What the requests must share is what the step itself shares: image size, step count / schedule
+        (DPM++ 2M, `sampler_opt`), guidance scale.
+
+        Every request keeps the arithmetic of its own one-image call: the rows are laid out `[u_0..u_{k-1}, c_0..c_{k-1}]`
+        (model_k_diffusion.py:1021,1097), request i's std group is rows {i, k + i} (`n_std_groups = k`: the std of
+        attention_modify.py:96 taken over ONE image's rows), its region tables ride on exactly those two rows
+        (quirk q1: both carry the cond table), and nothing else in the UNet couples rows - so image i equals the result of
+        `txt2img(**requests[i])` to launch-geometry rounding (tests/test_full_size_parity_gpu.py::
+        test_coalesced_requests_equal_their_single_runs), while every kernel of the step runs on k times the rows.
+
+        requests: list of dicts with `prompt_embeds` [1, S, ctx], `negative_prompt_embeds` [1, S, ctx], `text_input_ids`
+        ([negative ids, positive ids] or None), `region_map_state` (the UI's {phrase: {map, weight, mask_outsides}} or None) and
+        `latents` [1, 4, h/8, w/8] (or `generator`).  Returns the list of per-request outputs (`latent_to_image`)."""
+        k = len(requests)
+        if k < 1:
+            raise ValueError("txt2img_coalesced: no requests")
+        if guidance_scale <= 1.0 or self.v_prediction:
+            raise NotImplementedError("coalesced requests run the fused classifier-free-guidance loop (guidance_scale > 1, eps-prediction)")
+        device = self._execution_device
+        self._do_classifier_free_guidance = True
+        self._added_cond_kwargs = None
+        dt = self.unet.dtype
+        neg = torch.cat([r["negative_prompt_embeds"] for r in requests]).to(device=device, dtype=dt)
+        pos = torch.cat([r["prompt_embeds"] for r in requests]).to(device=device, dtype=dt)
+        if neg.shape != pos.shape or pos.shape[0] != k:
+            raise ValueError("txt2img_coalesced: one [1, S, ctx] prompt / negative prompt pair per request, equal S")
+        text = torch.cat([neg, pos])                                                                         # [u_0.., c_0..]
+        sigmas = self._schedule(num_inference_steps, sampler_opt or {}, device, dt)
+        lats = []
+        for r in requests:
+            lats.append(self.prepare_latents(1, self.unet.config.in_channels, height, width, dt, device, r.get("generator"),
+                                             r.get("latents")))
+        latents = torch.cat(lats) * (sigmas[0] ** 2 + 1) ** 0.5                                              # :1043
+        # per-request tables {L: [2, L, S]} (rows u, c) -> {L: [2k, L, S]} in the batch's row order
+        per = [encode_region_map(self, r.get("region_map_state"), width=width, height=height, num_images_per_prompt=1,
+                                 text_ids=r.get("text_input_ids") or [None, None]) for r in requests]
+        region_state = self._coalesce_region_tables(per)
+        latents = self._denoise_fused(latents, sigmas, text, region_state, weight_func, guidance_scale, k,
+                                      {} if cross_attention_kwargs is None else cross_attention_kwargs, start_time, timeout, slot=slot)
+        return [self.latent_to_image(latents[i:i + 1], output_type) for i in range(k)]
+
+    @staticmethod
+    def _coalesce_region_tables(per):
+        """per-request tables [{L: [2, L, S]} (rows uncond, cond) or a non-dict] -> ONE {L: [2k, L, S]} in the batch's row order
+        [u_0..u_{k-1}, c_0..c_{k-1}]: the kernels read table row b for batch row b (repeat_interleave(w, H) of
+        attention_modify.py:97-99 with Bw == Bc).  A request without masks rides along with zero tables (quirk q2: the region
+        path with a zero bias is the plain one); no request with masks -> the first request's non-dict state (region path off)."""
+        has = [isinstance(t, dict) and bool(t) for t in per]
+        if not any(has):
+            return per[0]
+        ref = per[has.index(True)]
+        per = [t if h else {L: torch.zeros_like(w) for L, w in ref.items()} for t, h in zip(per, has)]
+        for t in per:
+            if sorted(t) != sorted(ref) or any(t[L].shape != ref[L].shape or t[L].shape[0] != 2 for L in ref):
+                raise ValueError("txt2img_coalesced: the requests' region tables differ in levels / shape (same image size and prompt length needed)")
+        return {L: torch.cat([t[L][0:1] for t in per] + [t[L][1:2] for t in per]) for L in ref}
+
     def get_sampler_extra_args_i2i(self, sigmas, steps, sampler_opt, latents, seed, func):
         """reference :916-941"""
         params = inspect.signature(func).parameters

@@ -505,6 +505,83 @@ def test_sd15_25_step_loop_full_size_vs_oracle(sd15, profile):
     assert err.mean().item() < FINAL_LATENT_TOL_MEAN * scale, (err.mean().item(), scale)
 
 
+def _requests(n):
+    """n DIFFERENT batch-1 requests at 512x512: request 0 = configs[1]'s (2 masks, seed-7 embeddings, seed-1000 latent); the others
+    their own embeddings, mask count (1, 4, 2, ...) and latent"""
+    reqs = []
+    for i in range(n):
+        emb, ids, state, _ = _inputs(512, (2, 1, 4, 2, 1, 4, 2, 1)[i % 8])
+        if i:
+            emb = torch.randn(2, 77, 768, generator=torch.Generator().manual_seed(70 + i))
+        reqs.append({"prompt_embeds": emb[1:2].half(), "negative_prompt_embeds": emb[0:1].half(), "text_input_ids": ids,
+                     "region_map_state": state, "latents": _latent(i)[None].half()})
+    return reqs
+
+
+def test_coalesced_requests_equal_their_single_runs(sd15):
+    """Serving mode `txt2img_coalesced`: THREE different concurrent requests (2 / 1 / 4 masks, own prompts and latents) in one
+    captured step per sigma.  Image i of the coalesced run equals request i's own `txt2img` call - its std group is rows {i, 3 + i},
+    its tables ride on those rows - up to launch-geometry rounding (other grids / split counts at Bc = 6): 2e-3 of the latent range
+    after 3 steps, the bound of the batch-vs-single checks above; and request 0, whose inputs are configs[1]'s, is within the
+    3-step oracle bound."""
+    pipe = sd15.pipe
+    reqs = _requests(3)
+    kw = dict(height=512, width=512, num_inference_steps=25, guidance_scale=7.5, output_type="latent", sampler_opt={"scheduler": "karras"})
+    sig = pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
+    # 3-step truncation through the same entry point: a 25-step schedule cut after 3 steps (the schedule is an argument of the loop)
+    cut = {"orig": pipe._schedule}
+
+    def first3(steps, params, device, dtype):
+        s = cut["orig"](steps, params, device, dtype)[:4].clone()
+        return s
+
+    pipe._schedule = first3
+    try:
+        got = [o.float().cpu() for o in pipe.txt2img_coalesced([{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in r.items()} for r in reqs], **kw)]
+        singles = []
+        for r in reqs:
+            singles.append(pipe.txt2img(None, latents=r["latents"].cuda(), region_map_state=r["region_map_state"],
+                                        sampler_name="sample_dpmpp_2m", prompt_embeds=r["prompt_embeds"].cuda(),
+                                        negative_prompt_embeds=r["negative_prompt_embeds"].cuda(), text_input_ids=r["text_input_ids"],
+                                        **kw)[0].float().cpu())
+    finally:
+        del pipe._schedule                                      # back to the class's method
+    scale = max(s_.abs().max().item() for s_ in singles)
+    for i, (g_, s_) in enumerate(zip(got, singles)):
+        d = (g_ - s_).abs().max().item()
+        print(f"coalesced request {i}: vs its own txt2img call {d:.3e} (range {scale:.2f})")
+        assert g_.shape == (1, 4, 64, 64) and torch.isfinite(g_).all()
+        assert d < 2e-3 * scale, (i, d, scale)
+    assert (got[0] - got[1]).abs().max().item() > 0.1 * scale          # (the requests ARE different)
+    emb, ids, state, _ = _inputs(512, 2)
+    rs = _region_tables(pipe, state, 512, ids)
+    ref = _oracle_loop(sd15, _latent(0)[None].half(), sig, torch.cat([emb[0:1], emb[1:2]]).half(), rs, 3)
+    e = (got[0] - ref).abs()
+    print(f"coalesced request 0 vs oracle (3 steps): max {e.max().item():.3e} mean {e.mean().item():.3e}")
+    assert e.max().item() < 2.5e-3 * ref.abs().max().item()
+
+
+def test_coalesced_pair_25_steps_image0_vs_oracle(sd15):
+    """configs[1]'s request coalesced with a second, different request (k = 2): all 25 DPM++ 2M Karras steps; image 0 against the
+    fp32 oracle's 25-step latents of the ONE-image run - the stated end-to-end tolerance (8e-3 max / 1e-3 mean of range) holds for
+    a request that shared its steps with another one."""
+    reqs = _requests(2)
+    emb, ids, state, _ = _inputs(512, 2)
+    rs = _region_tables(sd15.pipe, state, 512, ids)
+    sig = sd15.pipe.get_sigmas(25, {"scheduler": "karras"}).half().float().tolist()
+    ref = _oracle_final_latents(sd15, _latent(0)[None], sig, torch.cat([emb[0:1], emb[1:2]]), rs)
+    got = sd15.pipe.txt2img_coalesced([{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in r.items()} for r in reqs], height=512, width=512,
+                                      num_inference_steps=25, guidance_scale=7.5, output_type="latent",
+                                      sampler_opt={"scheduler": "karras"})
+    g0 = got[0].float().cpu()
+    scale = ref.abs().max().item()
+    err = (g0 - ref).abs()
+    print(f"coalesced pair, image 0 after 25 steps: max/range {err.max().item() / scale:.2e} mean/range {err.mean().item() / scale:.2e}")
+    assert torch.isfinite(got[1]).all()
+    assert err.max().item() < FINAL_LATENT_TOL_MAX * scale, (err.max().item(), scale)
+    assert err.mean().item() < FINAL_LATENT_TOL_MEAN * scale, (err.mean().item(), scale)
+
+
 _ORACLE_25 = {}
 
 

@@ -634,3 +634,42 @@ def test_weight_func_key_is_by_value_where_the_callable_allows():
     box = [2.0]
     f1, f2 = (lambda w, s, qk: w * s * box[0] * qk.std()), (lambda w, s, qk: w * s * box[0] * qk.std())
     assert P._weight_func_key(f1) == id(f1) and P._weight_func_key(f2) == id(f2)        # a list cell: by identity
+
+
+def test_weight_func_key_falls_back_to_identity_for_mutable_captures():
+    """round-3 advisor: two closures over ONE mutable object that hashes by identity must not share a captured step (scalars
+    read from the object are baked into the capture), and the key must not keep such an object alive"""
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import StableDiffusionPipeline as P
+
+    class Knob:                              # hashable by identity, mutable
+        gain = 2.0
+
+    knob = Knob()
+    f1, f2 = (lambda w, s, qk: w * s * knob.gain * qk.std()), (lambda w, s, qk: w * s * knob.gain * qk.std())
+    assert P._weight_func_key(f1) == id(f1) and P._weight_func_key(f2) == id(f2)
+    tup = (1.5, "a", None, (2, True))        # tuples of immutable scalars stay by value
+
+    def make(c):
+        return lambda w, s, qk: w * s * c[0] * qk.std()
+
+    assert P._weight_func_key(make(tup)) == P._weight_func_key(make((1.5, "a", None, (2, True))))
+    assert isinstance(P._weight_func_key(make(tup)), tuple)
+
+
+def test_coalesced_requests_table_row_order():
+    """txt2img_coalesced: per-request tables [u, c] become ONE table in the batch's row order [u_0..u_{k-1}, c_0..c_{k-1}] (the
+    kernels read table row b for batch row b); a request without masks rides along with zeros; mismatched levels are refused"""
+    from diffusionspatialcontrol_amd.modules.model_k_diffusion import StableDiffusionPipeline as P
+    mk = lambda v: {16: torch.full((2, 16, 77), float(v)), 4: torch.full((2, 4, 77), float(v) + 0.5)}      # noqa: E731
+    t0, t1, t2 = mk(1), mk(2), mk(3)
+    t1[16][0] += 10                                           # make u and c rows distinguishable
+    rs = P._coalesce_region_tables([t0, t1, t2])
+    assert sorted(rs) == [4, 16] and rs[16].shape == (6, 16, 77)
+    assert [float(rs[16][i, 0, 0]) for i in range(6)] == [1.0, 12.0, 3.0, 1.0, 2.0, 3.0]
+    assert [float(rs[4][i, 0, 0]) for i in range(6)] == [1.5, 2.5, 3.5, 1.5, 2.5, 3.5]
+    none = torch.FloatTensor(0)                               # encode_region_map's "no table" value
+    rs = P._coalesce_region_tables([none, t1])
+    assert [float(rs[16][i, 0, 0]) for i in range(4)] == [0.0, 12.0, 0.0, 2.0]
+    assert P._coalesce_region_tables([none, none]) is none
+    with pytest.raises(ValueError):
+        P._coalesce_region_tables([t0, {16: torch.zeros(2, 16, 77)}])
