@@ -140,6 +140,8 @@ def load_library():
         lib.dsc_set_tuning_profile({"latency": 0, "throughput": 1}[os.environ["DSC_TUNING_PROFILE"]])
     if os.environ.get("DSC_CONV_RING"):                        # A/B switch: weight-tile ring depth of the 3x3 convolution (3 / 9)
         lib.dsc_debug_set_conv_ring(int(os.environ["DSC_CONV_RING"]))
+    if os.environ.get("DSC_GEMM_WIDE_MIN"):                    # A/B switch: workgroups a grid must keep for 128-column GEMM tiles
+        lib.dsc_debug_set_gemm_stages(-int(os.environ["DSC_GEMM_WIDE_MIN"]))
     if os.environ.get("DSC_CONV_K2"):                          # A/B switch: K-split eight-wave convolution (0 never, 1 grids <= 256 workgroups, 2 always)
         lib.dsc_debug_set_conv_ring(500 + int(os.environ["DSC_CONV_K2"]))
     if os.environ.get("DSC_GN_MODE"):                          # A/B switch: GroupNorm kernel selection (dsc_debug_set_gn_mode)

@@ -71,6 +71,7 @@ struct GemmParams {
     // that has a row per CFG branch): row m adds residual row m % res_rows; res_rows % BM == 0, so a row tile lies in one copy
     int res_rows; FastDiv fd_res;
     long long* stamps;           // diagnostics (dsc_debug_set_gemm_stamps): 8 x int64 per workgroup, NULL in normal calls
+    int nt_store;                // GEGLU: the hidden tensor (written once, read once by the next GEMM) with non-temporal stores
 };
 
 // DMA one [ROWS x 64] K-tile into LDS: piece = 8 rows x 128 B; lane l -> row l/8, LDS chunk l%8 holds global chunk (l%8)^((row>>1)&7)
@@ -321,7 +322,9 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                     // diffusers: proj output is an fp16 tensor; hidden * gelu(gate) with gelu's result in fp16
                     o[j] = (half_t)((float)(half_t)hid * (float)(half_t)gelu_erf((float)(half_t)gate));
                 }
-                *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
+                h8_t* dst = reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8);
+                if (p.nt_store) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
             }
         }
     } else {
@@ -442,18 +445,22 @@ int g_gemm_stages = 0;           // diagnostics (dsc_debug_set_gemm_stages): 0 =
 int g_gemm_bm = 0;               // ... (stages / 10 of the same call): 0 = default, 64 / 128 = forced tile height
 int g_gemm_loaders = 0;          // ... (stages / 10000 % 10): 0 = default (loader waves for the 64-row tiles), 4 = for every tile, 9 = never
 int g_gemm_xcd = 0;              // ... (stages / 1000000): 0 = by shape, 1 = plain blockIdx order, 2 = the XCD-aware order everywhere
+int g_gemm_wide_min = 512;       // plain GEMMs take 128-column tiles when that leaves at least this many workgroups (linear_impl)
+int g_gemm_ntstore = 0;          // ... (stages / 10000000 % 10): 1 = non-temporal stores of the GEGLU output
 int g_gemm_nt = 0;               // ... (stages / 100000): 0 = default (128-column tiles for the GEGLU GEMMs), 1 = never, 2 = wherever N allows
 
 }  // namespace
 
 extern "C" void dsc_debug_set_gemm_stamps(void* device_buffer) { g_gemm_stamps = static_cast<long long*>(device_buffer); }
 extern "C" void dsc_debug_set_gemm_stages(int stages) {
+    if (stages < 0) { g_gemm_wide_min = -stages; return; }      // (negative: the workgroup threshold of the 128-column rule)
     // stages % 10: ring depth (2, 3; else default); stages / 10: tile height (64, 128; else default) - e.g. 640 + 3
     const int bm = (stages / 10) % 1000, st = stages % 10;
     g_gemm_stages = (st == 2 || st == 3) ? st : 0;
     g_gemm_bm = (bm == 64 || bm == 128) ? bm : 0;
     const int ld = stages / 10000 % 10, nt = stages / 100000 % 10;
-    g_gemm_xcd = stages / 1000000 <= 2 ? stages / 1000000 : 0;
+    g_gemm_xcd = stages / 1000000 % 10 <= 2 ? stages / 1000000 % 10 : 0;
+    g_gemm_ntstore = stages / 10000000 % 10 == 1 ? 1 : 0;
     g_gemm_loaders = (ld == 4 || ld == 9) ? ld : 0;
     g_gemm_nt = (nt == 1 || nt == 2) ? nt : 0;
 }
@@ -517,6 +524,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     if (M > (1ll << 30)) return DSC_ERR_UNSUPPORTED;
     GemmParams p{};
     p.stamps = g_gemm_stamps;
+    p.nt_store = g_gemm_ntstore;
     p.x = static_cast<const half_t*>(x); p.w = static_cast<const half_t*>(w);
     p.bias = static_cast<const half_t*>(bias); p.res = static_cast<const half_t*>(residual);
     p.out = static_cast<half_t*>(out);
@@ -586,7 +594,14 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // 128-column tiles (two stages of 32 KiB, two workgroups per CU) where the grid still gives every CU a workgroup: the
     // GEGLU GEMMs (N/2 = 1280 / 2560 / 5120 -> 1280 / 640 / 320 workgroups)
     const bool wide_ok = bm == 128 && N % 128 == 0 && (!geglu || (N / 2) % 64 == 0) && (g_gemm_stages == 0 || g_gemm_stages == 2) && g_gemm_loaders != 4;
-    const bool wide = wide_ok && p.splits == 1 && (g_gemm_nt == 2 || (g_gemm_nt == 0 && geglu && (long long)mb * (N / 128) >= 256));
+    // ... and, round 4, every plain GEMM whose grid stays full with them (throughput tier: 8 images per generation, coalesced
+    // requests): 128 x 128 tiles halve the activation panel's trips through L2 -> LDS.  At 8 images per generation 15.3 -> 17.8
+    // images/s with them everywhere; at batch 1 the same tiles lose (too few workgroups), hence a rule on the grid they leave:
+    // g_gemm_wide_min workgroups (dsc_debug_set_gemm_stages(-n) sets it; tools/ab_bench8.sh).  Not with GroupNorm partial sums
+    // (gn_tile_partials is written for 64-column tiles).
+    const long long wide_wgs = (long long)mb * (N / 128);
+    const bool wide = wide_ok && p.splits == 1 && !gn &&
+                      (g_gemm_nt == 2 || (g_gemm_nt == 0 && (geglu ? wide_wgs >= 256 : wide_wgs >= g_gemm_wide_min)));
     if (wide) {
         nb = N / 128;
         p.total = mb * nb;

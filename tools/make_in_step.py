@@ -19,6 +19,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# where the stamped JSON / CSV copies go: profiles/ here; on the GPU box a directory under gpurun_out/ (only that comes back)
+OUT = os.environ.get("DSC_PROFILES_DIR") or os.path.join(ROOT, "profiles")
 # (substring of the demangled name, grid filter on Grid_Size_X or None, key on the bench line)
 WANT = [("xp_fwd<3,", None, "xp_fwd"), ("xp_stats<3,", None, "xp_stats"), ("self_attn_fwd<3, 8", None, "self_attn_fwd"),
         ("conv3x3_kernel<16, 3, 0>", "81920", "conv3x3_320_320_64x64")]
@@ -65,7 +67,7 @@ def main():
            "step_kernel_time_ms": round(step_ns / 1e6, 4), "kernels_per_step": (hi - lo) / 20.0, "kernels": {}}
     for k, pops in acc.items():
         rec["kernels"][k] = {p: {"avg_us": round(v[0] / v[1], 3), "launches": v[1]} for p, v in pops.items() if v[1]}
-    json.dump(rec, open(os.path.join(ROOT, "profiles", "in_step_kernels.json"), "w"), indent=1)
+    json.dump(rec, open(os.path.join(OUT, "in_step_kernels.json"), "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
 

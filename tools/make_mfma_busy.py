@@ -19,6 +19,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# where the stamped JSON / CSV copies go: profiles/ here; on the GPU box a directory under gpurun_out/ (only that comes back)
+OUT = os.environ.get("DSC_PROFILES_DIR") or os.path.join(ROOT, "profiles")
 
 KEYS = [("xp_fwd<3", "xp_fwd"), ("xp_stats<3", "xp_stats"), ("self_attn_fwd<3", "self_attn_fwd"),
         ("conv3x3_kernel", None), ("gemm_tn_f16", None)]
@@ -71,8 +73,8 @@ def main():
             if c in avg:
                 e[c] = round(avg[c])
         rec["kernels"][key] = e
-    json.dump(rec, open(os.path.join(ROOT, "profiles", "pmc_mfma_busy.json"), "w"), indent=1)
-    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_sq_counters_raw.csv"), "w", newline="") as f:      # this package's kernels only
+    json.dump(rec, open(os.path.join(OUT, "pmc_mfma_busy.json"), "w"), indent=1)
+    with open(os.path.join(OUT, f"{tag}_pmc_sq_counters_raw.csv"), "w", newline="") as f:      # this package's kernels only
         wr = csv.DictWriter(f, fieldnames=rdr.fieldnames)
         wr.writeheader()
         wr.writerows(kept)

@@ -19,6 +19,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# where the stamped JSON / CSV copies go: profiles/ here; on the GPU box a directory under gpurun_out/ (only that comes back)
+OUT = os.environ.get("DSC_PROFILES_DIR") or os.path.join(ROOT, "profiles")
 Bc, H, L, S, d = 2, 8, 4096, 77, 40                      # tools/pmc_xattn.py's shape
 C = H * d
 N_COLD = 12                                              # its first 12 launch pairs follow a cache-evicting fill
@@ -67,9 +69,9 @@ def main():
     rec["kernel"] = fwd_key
     how["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/pmc_xattn.py), averages over the "
                    f"{N_COLD} launches that follow a 512 MiB fill")
-    json.dump(rec, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-    shutil.copy(fpath, os.path.join(ROOT, "profiles", f"{tag}_pmc_xattn_FETCH_SIZE.csv"))
-    shutil.copy(wpath, os.path.join(ROOT, "profiles", f"{tag}_pmc_xattn_WRITE_SIZE.csv"))
+    json.dump(rec, open(os.path.join(OUT, "pmc_traffic.json"), "w"), indent=1)
+    shutil.copy(fpath, os.path.join(OUT, f"{tag}_pmc_xattn_FETCH_SIZE.csv"))
+    shutil.copy(wpath, os.path.join(OUT, f"{tag}_pmc_xattn_WRITE_SIZE.csv"))
     print(json.dumps(rec, indent=1))
 
 
