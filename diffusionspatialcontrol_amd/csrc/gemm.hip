@@ -595,10 +595,12 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // GEGLU GEMMs (N/2 = 1280 / 2560 / 5120 -> 1280 / 640 / 320 workgroups)
     const bool wide_ok = bm == 128 && N % 128 == 0 && (!geglu || (N / 2) % 64 == 0) && (g_gemm_stages == 0 || g_gemm_stages == 2) && g_gemm_loaders != 4;
     // ... and, round 4, every plain GEMM whose grid stays full with them (throughput tier: 8 images per generation, coalesced
-    // requests): 128 x 128 tiles halve the activation panel's trips through L2 -> LDS.  At 8 images per generation 15.3 -> 17.8
-    // images/s with them everywhere; at batch 1 the same tiles lose (too few workgroups), hence a rule on the grid they leave:
-    // g_gemm_wide_min workgroups (dsc_debug_set_gemm_stages(-n) sets it; tools/ab_bench8.sh).  Not with GroupNorm partial sums
-    // (gn_tile_partials is written for 64-column tiles).
+    // requests): 128 x 128 tiles halve the activation panel's trips through L2 -> LDS.  Measured end to end (tools/ab_benchk.sh,
+    // one box, images/s at 8 / 4 / 2 images per generation): never 16.66 / 14.15 / 11.76, grids of >= 512 workgroups 16.75 /
+    // 14.62 / 11.78, >= 256: 16.61 / 14.37 / 11.84, >= 64: 16.12 / 14.70 / 11.81 - a +3 % at 4 images, noise elsewhere; batch 1 has
+    // no such grid (same bits either way: the accumulation order per element does not depend on the tile).  g_gemm_wide_min
+    // workgroups (dsc_debug_set_gemm_stages(-n) sets it).  Not with GroupNorm partial sums (gn_tile_partials is written for
+    // 64-column tiles).
     const long long wide_wgs = (long long)mb * (N / 128);
     const bool wide = wide_ok && p.splits == 1 && !gn &&
                       (g_gemm_nt == 2 || (g_gemm_nt == 0 && (geglu ? wide_wgs >= 256 : wide_wgs >= g_gemm_wide_min)));

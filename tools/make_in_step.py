@@ -63,7 +63,7 @@ def main():
     step_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[lo + 1:hi + 1]) / 20.0
     rec = {"csrc_sha16": csrc_sha16(), "from": f"profiles/{tag}_bench_kernel_stats.csv / {tag}_step_breakdown.txt (same trace)",
            "command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline "
-                      "--no-batched-roofline --in-flight 1",
+                      "--no-batched-roofline --no-coalesced --in-flight 1",
            "step_kernel_time_ms": round(step_ns / 1e6, 4), "kernels_per_step": (hi - lo) / 20.0, "kernels": {}}
     for k, pops in acc.items():
         rec["kernels"][k] = {p: {"avg_us": round(v[0] / v[1], 3), "launches": v[1]} for p, v in pops.items() if v[1]}
