@@ -496,9 +496,22 @@ __device__ __forceinline__ void wait_step_k2(int t) {
 
 struct Frags2 { h8_t w[2], x0[2], x1[2]; };
 
-template <int TW, int S>
-__global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
+// GB = 1 (nine-stage ring only): ONE barrier per filter row (three taps) instead of one per tap.  A barrier has two jobs here -
+// publish freshly landed tiles and prove a stage is no longer read before it is refilled - and with nine stages both can be done
+// for three tiles at a time: at the barrier in front of taps 3g..3g+2 the tiles of those taps and of the next one are landed
+// (the fragments of step j+1 are read during step j), the stages of the three tiles before are refilled with the tiles seven to
+// nine steps ahead.  Inside a group the waves free-run (only their own lgkmcnt waits); the same arithmetic, the same bits.
+// NLOAD = 4 (with GB = 1): four more waves that issue ALL the DMA of the loop - the four-wave kernel's shares: two weight pieces per
+// tile and seven halo pieces per slice each - and nothing else; the eight computing waves then contain no vector-memory
+// instruction between their prologue and their stores (a DMA instruction holds its wave's issue port for 60-200 cycles).  Three
+// waves per SIMD: 168 registers each.
+template <int TW, int S, int GB = 0, int NLOAD = 0>
+__global__ __launch_bounds__(T2 + 64 * NLOAD, (NLOAD ? 3 : 2)) void conv3x3_k2_kernel(ConvParams p) {
+    static_assert(NLOAD == 0 || (NLOAD == 4 && GB == 1), "loader waves exist for the grouped-barrier form");
+    constexpr bool LOADER = NLOAD > 0;
     static_assert(S == 3 || S == 9, "the ring depth must divide the 9 taps");
+    static_assert(GB == 0 || S == 9, "grouped barriers need the nine-stage ring");
+    constexpr int NPRE = GB ? 7 : S;                         // weight tiles issued by the prologue
     constexpr int kAOff = a_off(S), kPadOff = pad_off(S);
     constexpr int NSB = 16 / TW;
     constexpr int HWD = TW + 2;
@@ -511,9 +524,11 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int lane = threadIdx.x & 63, wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_loader = LOADER && wave_all >= 8;
+    const int wave8 = wave_all & 7;                          // (a loader's index, 0..3, in its low bits)
     const int grp = wave8 >> 2;                              // K half of this wave: k-steps 2 grp, 2 grp + 1
-    const int wave = wave8 & 3;                              // output quadrant
+    const int wave = wave8 & 3;                              // output quadrant / loader index
     const int r = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -538,17 +553,26 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
 
-    // ---- weight DMA: ONE piece (8 rows x 128 B) per wave and tile
-    unsigned wvoff;
-    {
-        const int row = wave8 * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        wvoff = ((unsigned)(n0 + row) * 9u * (unsigned)p.Cin + chunk * 8) * 2u;
-    }
-    auto issue_b = [&](unsigned soff, int stage) { dma16(wr, wvoff, soff, kRingOff + stage * kBStageBytes + wave8 * 1024); };
-    auto tile_soff = [&](int c, int t) { return ((unsigned)t * (unsigned)p.Cin + (unsigned)c * BK) * 2u; };
+    // ---- weight DMA: ONE piece (8 rows x 128 B) per wave and tile; with loader waves two per loader (pieces wave, wave + 4)
+    constexpr int WP = LOADER ? 2 : 1, WSTEP = LOADER ? 4 : 8;
+    const int dw = LOADER ? wave : wave8;                    // this wave's index among the DMA-issuing waves
+    unsigned wvoff[WP];
 #pragma unroll
-    for (int k = 0; k < S; ++k) issue_b(tile_soff(cb, k), k);
+    for (int pc = 0; pc < WP; ++pc) {
+        const int row = (pc * WSTEP + dw) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        wvoff[pc] = ((unsigned)(n0 + row) * 9u * (unsigned)p.Cin + chunk * 8) * 2u;
+    }
+    auto issue_b = [&](unsigned soff, int stage) {
+#pragma unroll
+        for (int pc = 0; pc < WP; ++pc) dma16(wr, wvoff[pc], soff, kRingOff + stage * kBStageBytes + (pc * WSTEP + dw) * 1024);
+    };
+    const bool dma_wave = !LOADER || is_loader;
+    auto tile_soff = [&](int c, int t) { return ((unsigned)t * (unsigned)p.Cin + (unsigned)c * BK) * 2u; };
+    if (dma_wave) {
+#pragma unroll
+        for (int k = 0; k < NPRE; ++k) issue_b(tile_soff(cb, k), k);
+    }
 
     int ob[NSB], oy[NSB], ox[NSB];
 #pragma unroll
@@ -558,11 +582,13 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
         ob[sb] = g < p.nblk ? b : -1;
         oy[sb] = byy * 8; ox[sb] = (r2 - byy * p.bpr) * TW;
     }
-    // ---- halo DMA: 4 pieces per wave (pieces i * 8 + wave8; those past the halo land in the pad and read out of bounds)
-    unsigned aoff[4];
+    // ---- halo DMA: 4 pieces per wave (pieces i * 8 + wave8; those past the halo land in the pad and read out of bounds); with
+    // loader waves 7 per loader (pieces i * 4 + wave)
+    constexpr int AP = LOADER ? 7 : 4;
+    unsigned aoff[AP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int slot = (i * 8 + wave8) * 8 + (lane >> 3);
+    for (int i = 0; i < AP; ++i) {
+        const int slot = (i * WSTEP + dw) * 8 + (lane >> 3);
         unsigned off = kOob;
         if (slot < NSLOT) {
             const int sb = slot / HS, rem = slot % HS;
@@ -578,7 +604,7 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
         aoff[i] = off;
     }
     auto issue_a = [&](int i, int c, int ab) {
-        const int piece = i * 8 + wave8;
+        const int piece = i * WSTEP + dw;
         const unsigned dst = piece < NPIECE ? kAOff + ab * kABytes + piece * 1024 : kPadOff;
         dma16(xr, aoff[i], (unsigned)c * (BK * 2), dst);
     };
@@ -620,10 +646,45 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
 
+    if (dma_wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_a(i, cb, 0);
+        for (int i = 0; i < AP; ++i) issue_a(i, cb, 0);
+    }
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    if constexpr (LOADER) {
+        if (is_loader) {
+            // the loop's DMA with the computing waves' barriers: one per filter row.  At the barrier in front of taps t..t+2 the
+            // tiles up to j+3 have landed once only the previous group's issues (6 weight pieces, + 7 halo pieces when that group
+            // opened a slice) are outstanding
+            for (int c = cb; c < ce; ++c) {
+                const int jb = (c - cb) * 9;
+                const int cn = c + 1 < ce ? c + 1 : c;
+                const int P = (c - cb) & 1;
+#pragma unroll
+                for (int t = 0; t < 9; t += 3) {
+                    if (t == 3) wait_vm<13>(); else wait_vm<6>();
+                    __builtin_amdgcn_s_barrier();
+                    if (t == 0) {
+#pragma unroll
+                        for (int i = 0; i < AP; ++i) issue_a(i, cn, P ^ 1);
+                    }
+#pragma unroll
+                    for (int k = 7; k <= 9; ++k) {
+                        const int tt = t + k;
+                        const bool more = jb + tt < ns;
+                        const int c3 = tt >= 9 ? c + 1 : c, t3 = tt % 9;
+                        issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), tt % 9);
+                    }
+                }
+            }
+            __syncthreads();                                 // the epilogue's three workgroup barriers
+            __syncthreads();
+            __syncthreads();
+            if (p.gn_part) dsc_gn::gn_tile_partials_barriers();
+            return;
+        }
+    }
     Frags2 f[2];
     load_frags(f[0], 0, 0);
 
@@ -635,10 +696,38 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
         for (int t = 0; t < 9; ++t) {
             Frags2& cur = f[(P + t) & 1];
             Frags2& nxt = f[(P + t + 1) & 1];
-            wait_step_k2<S>(t);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GB) {
+                if (t % 3 == 0) {
+                    // tiles <= j+3 have landed once only the previous group's issues (3 weight pieces, + 4 halo pieces when that
+                    // group opened a slice) are outstanding
+                    if (!LOADER) { if (t == 3) wait_vm<7>(); else wait_vm<3>(); }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!LOADER) {
+                        if (t == 0) {
+#pragma unroll
+                            for (int i = 0; i < AP; ++i) issue_a(i, cn, P ^ 1);
+                        }
+#pragma unroll
+                        for (int k = 7; k <= 9; ++k) {       // tiles j+7..j+9 into the stages of tiles j-2..j
+                            const int tt = t + k;
+                            const bool more = jb + tt < ns;
+                            const int c3 = tt >= 9 ? c + 1 : c, t3 = tt % 9;
+                            issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), tt % 9);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                wait_step_k2<S>(t);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (t < 8) load_frags(nxt, P, t + 1);
             else load_frags(nxt, P ^ 1, 0);
 #pragma unroll
@@ -655,14 +744,16 @@ __global__ __launch_bounds__(T2, 2) void conv3x3_k2_kernel(ConvParams p) {
                 __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (t == 0) {
+            if constexpr (!GB) {
+                if (t == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) issue_a(i, cn, P ^ 1);
+                    for (int i = 0; i < AP; ++i) issue_a(i, cn, P ^ 1);
+                }
+                const bool more = jb + t + S < ns;
+                const int c3 = t + S >= 9 ? c + 1 : c, t3 = (t + S) % 9;
+                issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % S);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            const bool more = jb + t + S < ns;
-            const int c3 = t + S >= 9 ? c + 1 : c, t3 = (t + S) % 9;
-            issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % S);
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
     for (int c = cb; c < ce; ++c) {
@@ -825,6 +916,8 @@ int tile_width(int H, int W) {
 //   fixed     5 (launch, prologue, epilogue)
 //   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
 // e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
+int g_conv_ring9_always = 0;       // dsc_debug_set_conv_ring(800 / 801): grids of <= 256 workgroups take the nine-stage ring under the latency profile only / under both
+int g_conv_gb = 1;                 // dsc_debug_set_conv_ring(600 / 601 / 602): the K-split kernel's nine-stage form with one barrier per tap / per filter row / per filter row + four loader waves
 int g_conv_k2 = 0;                 // dsc_debug_set_conv_ring(500 / 501 / 502): K-split eight-wave kernel never (default: measured, no gain) / for grids of <= 256 workgroups / always
 int g_conv_loaders = 1;            // dsc_debug_set_conv_ring(400 / 401 / 402): nine-stage kernels without loader waves / by rule / always
 int g_conv_order = -1;             // dsc_debug_set_conv_ring(300 / 301): pixel tiles / channel blocks fastest within an XCD (-1: by shape)
@@ -874,7 +967,9 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
 extern "C" void dsc_debug_set_conv_ring(int stages) {
-    if (stages >= 500) g_conv_k2 = stages - 500;
+    if (stages >= 800) g_conv_ring9_always = stages - 800;
+    else if (stages >= 600) g_conv_gb = stages - 600;
+    else if (stages >= 500) g_conv_k2 = stages - 500;
     else if (stages >= 400) g_conv_loaders = stages - 400;
     else if (stages >= 300) g_conv_order = stages - 300;
     else if (stages >= 200) g_conv_small_step = (stages - 200) / 100.0;
@@ -984,7 +1079,9 @@ int conv_impl(const void* x, const void* w, const void* bias, const void* residu
                              reinterpret_cast<const void*>(&conv3x3_kernel<16, 9, 4>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9, 4>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         const void* fns2[] = {reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 3>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 3>),
-                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9>)};
+                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9>),
+                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9, 1>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9, 1>),
+                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9, 1, 4>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9, 1, 4>)};
         for (const void* f : fns2) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -998,7 +1095,7 @@ int conv_impl(const void* x, const void* w, const void* bias, const void* residu
     int ring = g_conv_ring;
     // ... and only while this stream owns the chip: with a second generation in flight the whole-LDS workgroups keep the other
     // stream's kernels off their CUs (dsc_set_tuning_profile)
-    if (ring != 3 && ring != 9) ring = (total <= 256 && g_dsc_tuning_profile == DSC_TUNE_LATENCY) ? 9 : 3;
+    if (ring != 3 && ring != 9) ring = (total <= 256 && (g_dsc_tuning_profile == DSC_TUNE_LATENCY || g_conv_ring9_always)) ? 9 : 3;
     // the nine-stage ring has the CU to itself anyway.  In the step: 16-wide tiles 29.2 -> 25.0 us (160 workgroups), 21.2 ->
     // 19.5 (64); the 8-wide kernel (8x8 level, two halo parities, 12 spilled registers at the 256 cap) 15.0 -> 16.0: not used
     const bool loaders = ring == 9 && (g_conv_loaders == 2 || (g_conv_loaders == 1 && tw == 16));
@@ -1009,10 +1106,14 @@ int conv_impl(const void* x, const void* w, const void* bias, const void* residu
     if (k2) {
         const dim3 block2(T2);
         if (tw == 16) {
-            if (ring == 9) DSC_LAUNCH((conv3x3_k2_kernel<16, 9>), grid, block2, (size_t)lds_bytes(9), st, p);
+            if (ring == 9 && g_conv_gb == 2) DSC_LAUNCH((conv3x3_k2_kernel<16, 9, 1, 4>), grid, dim3(T2 + 256), (size_t)lds_bytes(9), st, p);
+            else if (ring == 9 && g_conv_gb) DSC_LAUNCH((conv3x3_k2_kernel<16, 9, 1>), grid, block2, (size_t)lds_bytes(9), st, p);
+            else if (ring == 9) DSC_LAUNCH((conv3x3_k2_kernel<16, 9>), grid, block2, (size_t)lds_bytes(9), st, p);
             else DSC_LAUNCH((conv3x3_k2_kernel<16, 3>), grid, block2, (size_t)lds_bytes(3), st, p);
         } else {
-            if (ring == 9) DSC_LAUNCH((conv3x3_k2_kernel<8, 9>), grid, block2, (size_t)lds_bytes(9), st, p);
+            if (ring == 9 && g_conv_gb == 2) DSC_LAUNCH((conv3x3_k2_kernel<8, 9, 1, 4>), grid, dim3(T2 + 256), (size_t)lds_bytes(9), st, p);
+            else if (ring == 9 && g_conv_gb) DSC_LAUNCH((conv3x3_k2_kernel<8, 9, 1>), grid, block2, (size_t)lds_bytes(9), st, p);
+            else if (ring == 9) DSC_LAUNCH((conv3x3_k2_kernel<8, 9>), grid, block2, (size_t)lds_bytes(9), st, p);
             else DSC_LAUNCH((conv3x3_k2_kernel<8, 3>), grid, block2, (size_t)lds_bytes(3), st, p);
         }
     } else if (tw == 16) {

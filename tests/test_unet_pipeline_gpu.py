@@ -330,10 +330,16 @@ def test_conv3x3_k_split_eight_wave_form(ops, B, Cin, Cout, H, W, splits):
             lib.dsc_debug_set_conv_ring(ring)
             outs[ring] = ops.conv3x3(x, w, b, residual=r, splits=splits)
             assert torch.equal(outs[ring], ops.conv3x3(x, w, b, residual=r, splits=splits))
+        lib.dsc_debug_set_conv_ring(600)                          # nine stages, one barrier per tap (601, the default: per filter row)
+        outs["per tap"] = ops.conv3x3(x, w, b, residual=r, splits=splits)
+        lib.dsc_debug_set_conv_ring(602)                          # ... per filter row with four DMA-only loader waves
+        outs["loaders"] = ops.conv3x3(x, w, b, residual=r, splits=splits)
+        assert torch.equal(outs["loaders"], ops.conv3x3(x, w, b, residual=r, splits=splits))
     finally:
+        lib.dsc_debug_set_conv_ring(601)
         lib.dsc_debug_set_conv_ring(0)
         lib.dsc_debug_set_conv_ring(500 + int(os.environ.get("DSC_CONV_K2", "0")))
-    assert torch.equal(outs[3], outs[9])
+    assert torch.equal(outs[3], outs[9]) and torch.equal(outs["per tap"], outs[9]) and torch.equal(outs["loaders"], outs[9])
     for o in (four, outs[3]):
         assert torch.all((o.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3), (o.float() - ref).abs().max().item()
     assert (four.float() - outs[3].float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())

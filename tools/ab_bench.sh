@@ -10,7 +10,7 @@ for r in $(seq $reps); do
     read -r -a parts <<< "$spec"
     name=${parts[0]}
     ( for kv in "${parts[@]:1}"; do export "$kv"; done
-      timeout -k 10 300 python3 $root/bench.py --steps $steps --warmup 2 --no-cpu-baseline --no-batched-roofline $BENCH_ARGS > $root/$out/line_${name}_$r.json 2> $root/$out/err_${name}_$r.log ) || exit 1
+      timeout -k 10 300 python3 $root/bench.py --steps $steps --warmup 2 --no-cpu-baseline --no-batched-roofline --no-coalesced $BENCH_ARGS > $root/$out/line_${name}_$r.json 2> $root/$out/err_${name}_$r.log ) || exit 1
     python3 - $root/$out/line_${name}_$r.json $name $r <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -13,11 +13,9 @@ for (B, cin, cout, hw) in shapes:
     w = (torch.randn(cout, cin, 3, 3, device=dev) / (3 * cin ** 0.5)).half().contiguous(memory_format=torch.channels_last)
     fl = 2.0 * B * hw * hw * cin * cout * 9
     line = f"conv3x3 B{B} {cin:4d}->{cout:4d} @{hw:2d}:"
-    for k2 in (500, 502):
-        lib.dsc_debug_set_conv_ring(k2)
-        for ring in (9, 3):
-            lib.dsc_debug_set_conv_ring(ring)
-            t = tm_graph(lambda: ops.conv3x3(x, w, None))
-            line += f"  {'k2' if k2 == 502 else 'k1'} r{ring}: {t:6.1f} us ({fl/t/1e6:4.0f} TF)"
-    lib.dsc_debug_set_conv_ring(0); lib.dsc_debug_set_conv_ring(500)
+    for k2, ring, gb, name in ((500, 9, 601, "k1 r9"), (500, 3, 601, "k1 r3"), (502, 9, 600, "k2 r9 tap"), (502, 9, 601, "k2 r9 row"), (502, 9, 602, "k2 r9 row+ld")):
+        lib.dsc_debug_set_conv_ring(k2); lib.dsc_debug_set_conv_ring(ring); lib.dsc_debug_set_conv_ring(gb)
+        t = tm_graph(lambda: ops.conv3x3(x, w, None))
+        line += f"  {name}: {t:6.1f} ({fl/t/1e6:4.0f} TF)"
+    lib.dsc_debug_set_conv_ring(0); lib.dsc_debug_set_conv_ring(500); lib.dsc_debug_set_conv_ring(601)
     print(line, flush=True)
