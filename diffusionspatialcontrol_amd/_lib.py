@@ -142,12 +142,6 @@ def load_library():
         lib.dsc_debug_set_conv_ring(int(os.environ["DSC_CONV_RING"]))
     if os.environ.get("DSC_GEMM_WIDE_MIN"):                    # A/B switch: workgroups a grid must keep for 128-column GEMM tiles
         lib.dsc_debug_set_gemm_stages(-int(os.environ["DSC_GEMM_WIDE_MIN"]))
-    if os.environ.get("DSC_CONV_K2"):                          # A/B switch: K-split eight-wave convolution (0 never, 1 grids <= 256 workgroups, 2 always)
-        lib.dsc_debug_set_conv_ring(500 + int(os.environ["DSC_CONV_K2"]))
-    if os.environ.get("DSC_CONV_RING9_ALWAYS"):                # A/B switch: small grids' nine-stage ring under both tuning profiles
-        lib.dsc_debug_set_conv_ring(800 + int(os.environ["DSC_CONV_RING9_ALWAYS"]))
-    if os.environ.get("DSC_CONV_GB"):                          # A/B switch: K-split convolution, barrier per tap (0) / per filter row (1)
-        lib.dsc_debug_set_conv_ring(600 + int(os.environ["DSC_CONV_GB"]))
     if os.environ.get("DSC_GN_MODE"):                          # A/B switch: GroupNorm kernel selection (dsc_debug_set_gn_mode)
         lib.dsc_debug_set_gn_mode(int(os.environ["DSC_GN_MODE"]))
     if os.environ.get("DSC_GEMM_STAGES"):                      # A/B switch: K-tile ring depth of the hand-written GEMM (2 / 3)

@@ -460,415 +460,6 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (S == 3 || NLOAD ? 2 : 1)) void con
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// K-split form (round 4): the SAME 128-pixel x 64-channel tile, halo / ring layout and step sequence, run by EIGHT computing
-// waves - two per SIMD.  Waves 0-3 multiply the first 32 input channels of every (slice, tap) step (k-steps 0, 1), waves 4-7 the
-// last 32 (k-steps 2, 3); the two partial tiles meet in the fp32 LDS stage of the epilogue (first half + second half: a fixed
-// order).  Why: a workgroup alone on its CU ran a step in ~570 cycles against 256 cycles of MFMA - one wave per SIMD issuing 8
-// MFMAs, 12 ds_read_b128 and its DMA share in a serial chain ("40-channel convolution tiles") - and the grids
-// of <= 256 workgroups (the 640-channel convolutions at 32x32: 23 launches, 0.66 ms of a 4.7 ms step) have no second workgroup
-// to fill the gaps.  Here every SIMD holds two half-chains (4 MFMAs, 6 reads, one weight piece per step each): the fragment reads
-// per MFMA stay at 1.5, the LDS image and the traffic per step are unchanged, the DMA issue is spread over eight waves (no loader
-// waves needed).  Different summation order from the four-wave kernel -> its own bits; chosen by GRID SIZE only, so both tuning
-// profiles (ring depth 9 / 3) still give equal bytes.
-constexpr int T2 = 512;
-
-template <int S>
-constexpr int younger_dmas_k2(int t) {        // per wave and step: one weight piece (+ 4 halo pieces at tap 0)
-    int n = 0;
-    for (int i = 1; i <= S - 2; ++i) n += ((t - i) % 9 + 9) % 9 == 0 ? 5 : 1;
-    return n;
-}
-template <int S>
-__device__ __forceinline__ void wait_step_k2(int t) {
-    switch (t) {
-        case 0: wait_vm<younger_dmas_k2<S>(0)>(); break;
-        case 1: wait_vm<younger_dmas_k2<S>(1)>(); break;
-        case 2: wait_vm<younger_dmas_k2<S>(2)>(); break;
-        case 3: wait_vm<younger_dmas_k2<S>(3)>(); break;
-        case 4: wait_vm<younger_dmas_k2<S>(4)>(); break;
-        case 5: wait_vm<younger_dmas_k2<S>(5)>(); break;
-        case 6: wait_vm<younger_dmas_k2<S>(6)>(); break;
-        case 7: wait_vm<younger_dmas_k2<S>(7)>(); break;
-        default: wait_vm<younger_dmas_k2<S>(8)>(); break;
-    }
-}
-
-struct Frags2 { h8_t w[2], x0[2], x1[2]; };
-
-// GB = 1 (nine-stage ring only): ONE barrier per filter row (three taps) instead of one per tap.  A barrier has two jobs here -
-// publish freshly landed tiles and prove a stage is no longer read before it is refilled - and with nine stages both can be done
-// for three tiles at a time: at the barrier in front of taps 3g..3g+2 the tiles of those taps and of the next one are landed
-// (the fragments of step j+1 are read during step j), the stages of the three tiles before are refilled with the tiles seven to
-// nine steps ahead.  Inside a group the waves free-run (only their own lgkmcnt waits); the same arithmetic, the same bits.
-// NLOAD = 4 (with GB = 1): four more waves that issue ALL the DMA of the loop - the four-wave kernel's shares: two weight pieces per
-// tile and seven halo pieces per slice each - and nothing else; the eight computing waves then contain no vector-memory
-// instruction between their prologue and their stores (a DMA instruction holds its wave's issue port for 60-200 cycles).  Three
-// waves per SIMD: 168 registers each.
-template <int TW, int S, int GB = 0, int NLOAD = 0>
-__global__ __launch_bounds__(T2 + 64 * NLOAD, (NLOAD ? 3 : 2)) void conv3x3_k2_kernel(ConvParams p) {
-    static_assert(NLOAD == 0 || (NLOAD == 4 && GB == 1), "loader waves exist for the grouped-barrier form");
-    constexpr bool LOADER = NLOAD > 0;
-    static_assert(S == 3 || S == 9, "the ring depth must divide the 9 taps");
-    static_assert(GB == 0 || S == 9, "grouped barriers need the nine-stage ring");
-    constexpr int NPRE = GB ? 7 : S;                         // weight tiles issued by the prologue
-    constexpr int kAOff = a_off(S), kPadOff = pad_off(S);
-    constexpr int NSB = 16 / TW;
-    constexpr int HWD = TW + 2;
-    constexpr int HS = 10 * HWD;
-    constexpr int NSLOT = NSB * HS;
-    constexpr int NPIECE = (NSLOT + 7) / 8;
-    constexpr int NPAR = TW == 16 ? 1 : 2;
-    constexpr int MT1 = (32 / TW) * HWD * 128;
-    static_assert(NPIECE <= kAPiecesMax && NPIECE <= 32, "halo does not fit");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int lane = threadIdx.x & 63, wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool is_loader = LOADER && wave_all >= 8;
-    const int wave8 = wave_all & 7;                          // (a loader's index, 0..3, in its low bits)
-    const int grp = wave8 >> 2;                              // K half of this wave: k-steps 2 grp, 2 grp + 1
-    const int wave = wave8 & 3;                              // output quadrant / loader index
-    const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int total = p.mt * p.nt * p.splits;
-    const int per = gridDim.x >> 3;
-    const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (v >= total) return;
-    int bm, bn, sp;
-    if (p.order) {
-        const int rest = fdiv(v, p.fd_nt);
-        bn = v - rest * p.nt;
-        sp = fdiv(rest, p.fd_mt); bm = rest - sp * p.mt;
-    } else {
-        const int rest = fdiv(v, p.fd_mt);
-        bm = v - rest * p.mt;
-        sp = fdiv(rest, p.fd_nt); bn = rest - sp * p.nt;
-    }
-    const int n0 = bn * BN;
-    const int cb = sp * p.cps, ce = min(p.nc, cb + p.cps);
-    const int ns = (ce - cb) * 9;
-
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
-
-    // ---- weight DMA: ONE piece (8 rows x 128 B) per wave and tile; with loader waves two per loader (pieces wave, wave + 4)
-    constexpr int WP = LOADER ? 2 : 1, WSTEP = LOADER ? 4 : 8;
-    const int dw = LOADER ? wave : wave8;                    // this wave's index among the DMA-issuing waves
-    unsigned wvoff[WP];
-#pragma unroll
-    for (int pc = 0; pc < WP; ++pc) {
-        const int row = (pc * WSTEP + dw) * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        wvoff[pc] = ((unsigned)(n0 + row) * 9u * (unsigned)p.Cin + chunk * 8) * 2u;
-    }
-    auto issue_b = [&](unsigned soff, int stage) {
-#pragma unroll
-        for (int pc = 0; pc < WP; ++pc) dma16(wr, wvoff[pc], soff, kRingOff + stage * kBStageBytes + (pc * WSTEP + dw) * 1024);
-    };
-    const bool dma_wave = !LOADER || is_loader;
-    auto tile_soff = [&](int c, int t) { return ((unsigned)t * (unsigned)p.Cin + (unsigned)c * BK) * 2u; };
-    if (dma_wave) {
-#pragma unroll
-        for (int k = 0; k < NPRE; ++k) issue_b(tile_soff(cb, k), k);
-    }
-
-    int ob[NSB], oy[NSB], ox[NSB];
-#pragma unroll
-    for (int sb = 0; sb < NSB; ++sb) {
-        const int g = bm * NSB + sb;
-        const int b = fdiv(g, p.fd_bpi), r2 = g - b * p.bpi, byy = fdiv(r2, p.fd_bpr);
-        ob[sb] = g < p.nblk ? b : -1;
-        oy[sb] = byy * 8; ox[sb] = (r2 - byy * p.bpr) * TW;
-    }
-    // ---- halo DMA: 4 pieces per wave (pieces i * 8 + wave8; those past the halo land in the pad and read out of bounds); with
-    // loader waves 7 per loader (pieces i * 4 + wave)
-    constexpr int AP = LOADER ? 7 : 4;
-    unsigned aoff[AP];
-#pragma unroll
-    for (int i = 0; i < AP; ++i) {
-        const int slot = (i * WSTEP + dw) * 8 + (lane >> 3);
-        unsigned off = kOob;
-        if (slot < NSLOT) {
-            const int sb = slot / HS, rem = slot % HS;
-            const int hy = rem / HWD, hx = rem % HWD;
-            const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
-            const int y = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) - 1 + hy;
-            const int x = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) - 1 + hx;
-            if (b >= 0 && y >= 0 && y < p.H && x >= 0 && x < p.W) {
-                const int px = p.up ? (b * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1) : (b * p.H + y) * p.W + x;
-                off = ((unsigned)px * (unsigned)p.ldx + (((lane & 7) ^ halo_swz<TW>(hy, hx)) << 3)) * 2u;
-            }
-        }
-        aoff[i] = off;
-    }
-    auto issue_a = [&](int i, int c, int ab) {
-        const int piece = i * WSTEP + dw;
-        const unsigned dst = piece < NPIECE ? kAOff + ab * kABytes + piece * 1024 : kPadOff;
-        dma16(xr, aoff[i], (unsigned)c * (BK * 2), dst);
-    };
-    // ---- operand addresses of this wave's two k-steps
-    unsigned xaddr[NPAR][3][2], waddr[2], waddr_hi[2];
-    {
-        const int m = wm * 64 + r;
-        const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
-        const int slot00 = sb * HS + py * HWD + pxl;
-#pragma unroll
-        for (int par = 0; par < NPAR; ++par)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int sw = halo_swz<TW>(py + par, pxl + dx);
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    xaddr[par][dx][k] = (unsigned)(kAOff + (slot00 + dx) * 128 + (((2 * (2 * grp + k) + hh) ^ sw) << 4));
-            }
-        const int wrow = wn * 32 + r;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            waddr[k] = (unsigned)(kRingOff + wrow * 128 + (((2 * (2 * grp + k) + hh) ^ ((wrow >> 1) & 7)) << 4));
-            waddr_hi[k] = waddr[k] + 4 * kBStageBytes;
-        }
-    }
-    auto load_frags = [&](Frags2& f, int ab, int t) {
-        const int dy = t / 3, dx = t % 3;
-        const unsigned abase = ab * kABytes + dy * HWD * 128;
-        const int stg = t % S;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            f.w[k] = stg < 4 ? lds_read(waddr[k] + stg * kBStageBytes) : lds_read(waddr_hi[k] + (stg - 4) * kBStageBytes);
-            f.x0[k] = lds_read(xaddr[NPAR == 1 ? 0 : (dy & 1)][dx][k] + abase);
-            f.x1[k] = lds_read(xaddr[NPAR == 1 ? 0 : (dy & 1)][dx][k] + abase + MT1);
-        }
-    };
-
-    f16x_t acc[2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-
-    if (dma_wave) {
-#pragma unroll
-        for (int i = 0; i < AP; ++i) issue_a(i, cb, 0);
-    }
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if constexpr (LOADER) {
-        if (is_loader) {
-            // the loop's DMA with the computing waves' barriers: one per filter row.  At the barrier in front of taps t..t+2 the
-            // tiles up to j+3 have landed once only the previous group's issues (6 weight pieces, + 7 halo pieces when that group
-            // opened a slice) are outstanding
-            for (int c = cb; c < ce; ++c) {
-                const int jb = (c - cb) * 9;
-                const int cn = c + 1 < ce ? c + 1 : c;
-                const int P = (c - cb) & 1;
-#pragma unroll
-                for (int t = 0; t < 9; t += 3) {
-                    if (t == 3) wait_vm<13>(); else wait_vm<6>();
-                    __builtin_amdgcn_s_barrier();
-                    if (t == 0) {
-#pragma unroll
-                        for (int i = 0; i < AP; ++i) issue_a(i, cn, P ^ 1);
-                    }
-#pragma unroll
-                    for (int k = 7; k <= 9; ++k) {
-                        const int tt = t + k;
-                        const bool more = jb + tt < ns;
-                        const int c3 = tt >= 9 ? c + 1 : c, t3 = tt % 9;
-                        issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), tt % 9);
-                    }
-                }
-            }
-            __syncthreads();                                 // the epilogue's three workgroup barriers
-            __syncthreads();
-            __syncthreads();
-            if (p.gn_part) dsc_gn::gn_tile_partials_barriers();
-            return;
-        }
-    }
-    Frags2 f[2];
-    load_frags(f[0], 0, 0);
-
-    auto slice = [&](auto parity, int c) {
-        constexpr int P = decltype(parity)::value;
-        const int jb = (c - cb) * 9;
-        const int cn = c + 1 < ce ? c + 1 : c;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            Frags2& cur = f[(P + t) & 1];
-            Frags2& nxt = f[(P + t + 1) & 1];
-            if constexpr (GB) {
-                if (t % 3 == 0) {
-                    // tiles <= j+3 have landed once only the previous group's issues (3 weight pieces, + 4 halo pieces when that
-                    // group opened a slice) are outstanding
-                    if (!LOADER) { if (t == 3) wait_vm<7>(); else wait_vm<3>(); }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!LOADER) {
-                        if (t == 0) {
-#pragma unroll
-                            for (int i = 0; i < AP; ++i) issue_a(i, cn, P ^ 1);
-                        }
-#pragma unroll
-                        for (int k = 7; k <= 9; ++k) {       // tiles j+7..j+9 into the stages of tiles j-2..j
-                            const int tt = t + k;
-                            const bool more = jb + tt < ns;
-                            const int c3 = tt >= 9 ? c + 1 : c, t3 = tt % 9;
-                            issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), tt % 9);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                wait_step_k2<S>(t);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (t < 8) load_frags(nxt, P, t + 1);
-            else load_frags(nxt, P ^ 1, 0);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                acc[0] = mfma_32x32x16(cur.w[k], cur.x0[k], acc[0]);
-                acc[1] = mfma_32x32x16(cur.w[k], cur.x1[k], acc[1]);
-            }
-            // the six fragment reads of the next step two per gap in front of the first three MFMAs; the step's DMA pieces go out
-            // BEHIND its MFMAs (a DMA instruction holds the wave's issue port for 60-200 cycles: at the head of the step it
-            // delayed every wave's reads)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!GB) {
-                if (t == 0) {
-#pragma unroll
-                    for (int i = 0; i < AP; ++i) issue_a(i, cn, P ^ 1);
-                }
-                const bool more = jb + t + S < ns;
-                const int c3 = t + S >= 9 ? c + 1 : c, t3 = (t + S) % 9;
-                issue_b(more ? tile_soff(c3, t3) : tile_soff(c, t), t % S);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    for (int c = cb; c < ce; ++c) {
-        if ((c - cb) & 1) slice(std::integral_constant<int, 1>{}, c);
-        else slice(std::integral_constant<int, 0>{}, c);
-    }
-    // ---- epilogue.  The output pass is the four-wave kernel's: threads 0..255 own the (pixel, 8-channel chunk) pairs, four
-    // passes; waves 4-7 only contribute their partial tile and keep the barriers
-    const bool outp = threadIdx.x < T;
-    h8_t rpre[4];
-    h8_t bpre = {0, 0, 0, 0, 0, 0, 0, 0};
-    h8_t apre = {0, 0, 0, 0, 0, 0, 0, 0};
-    float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (outp) {
-        if (p.bias && p.splits == 1 && !p.nchw && n0 + (int)(threadIdx.x & 7) * 8 + 8 <= p.Cout)
-            bpre = *reinterpret_cast<const h8_t*>(p.bias + n0 + (threadIdx.x & 7) * 8);
-        if (p.add && ob[0] >= 0) apre = *reinterpret_cast<const h8_t*>(p.add + (long long)ob[0] * p.add_ld + n0 + (threadIdx.x & 7) * 8);
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) {
-            rpre[cidx] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            if (p.res && p.splits == 1 && !p.nchw) {
-                const int idx = threadIdx.x + cidx * T, m = idx >> 3, ch = idx & 7;
-                const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
-                const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
-                const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
-                long long gp = ((long long)b * p.H + yy) * p.W + xx;
-                bool live = b >= 0 && yy < p.H && xx < p.W && n0 + ch * 8 + 8 <= p.Cout;
-                if (p.sub2) { live = live && (p.sub2 == 1 ? !((yy | xx) & 1) : (yy & xx & 1) != 0); gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1); }
-                if (live) rpre[cidx] = *reinterpret_cast<const h8_t*>(p.res + gp * p.ldr + n0 + ch * 8);
-            }
-        }
-    }
-    __syncthreads();                                             // every wave is done with the halo / ring
-    float* stage = reinterpret_cast<float*>(smem);
-    if (grp == 1) {                                              // second K half first ...
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4x_t vv = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                *reinterpret_cast<f4x_t*>(stage + (wm * 64 + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh) = vv;
-            }
-    }
-    __syncthreads();
-    if (grp == 0) {                                              // ... the first half is added to it: result = first + second
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float* q = stage + (wm * 64 + mt * 32 + r) * kEpiStride + wn * 32 + 8 * g + 4 * hh;
-                const f4x_t o = *reinterpret_cast<const f4x_t*>(q);
-                const f4x_t vv = {acc[mt][4 * g] + o[0], acc[mt][4 * g + 1] + o[1], acc[mt][4 * g + 2] + o[2], acc[mt][4 * g + 3] + o[3]};
-                *reinterpret_cast<f4x_t*>(q) = vv;
-            }
-    }
-    __syncthreads();
-    if (outp) {
-#pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) {
-            const int idx = threadIdx.x + cidx * T, m = idx >> 3, ch = idx & 7;
-            const int sb = m / (8 * TW), py = (m % (8 * TW)) / TW, pxl = m % TW;
-            const int b = NSB == 1 ? ob[0] : (sb ? ob[NSB - 1] : ob[0]);
-            if (b < 0) continue;
-            const int yy = (NSB == 1 ? oy[0] : (sb ? oy[NSB - 1] : oy[0])) + py, xx = (NSB == 1 ? ox[0] : (sb ? ox[NSB - 1] : ox[0])) + pxl;
-            if (yy >= p.H || xx >= p.W) continue;
-            long long gp = ((long long)b * p.H + yy) * p.W + xx;
-            if (p.sub2) {
-                if (p.sub2 == 1 ? ((yy | xx) & 1) != 0 : (yy & xx & 1) == 0) continue;
-                gp = ((long long)b * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1);
-            }
-            const float* sp_ = stage + m * kEpiStride + ch * 8;
-            if (p.splits > 1) {
-                float* dst = p.ws + ((long long)sp * p.onpix + gp) * p.Cout + n0 + ch * 8;
-                *reinterpret_cast<f4x_t*>(dst) = *reinterpret_cast<const f4x_t*>(sp_);
-                *reinterpret_cast<f4x_t*>(dst + 4) = *reinterpret_cast<const f4x_t*>(sp_ + 4);
-            } else {
-                const int c0 = n0 + ch * 8;
-                if (c0 >= p.Cout) continue;
-                if (c0 + 8 <= p.Cout && !p.nchw) {
-                    const h8_t bv = bpre, rv = rpre[cidx];
-                    h8_t o;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        o[jj] = (half_t)(sp_[jj] + (float)bv[jj] + (float)apre[jj] + (float)rv[jj]);
-                        const float fv = (float)o[jj];
-                        gs[jj] += fv; gq[jj] += fv * fv;
-                    }
-                    *reinterpret_cast<h8_t*>(p.out + gp * p.ldo + c0) = o;
-                } else {
-                    const long long hw = p.onpix / p.B;
-                    const long long pin = gp - (long long)b * hw;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int c = c0 + jj;
-                        if (c < p.Cout) {
-                            float vv = sp_[jj] + (p.bias ? (float)p.bias[c] : 0.f);
-                            if (p.res) vv += (float)p.res[gp * p.ldr + c];
-                            if (p.nchw) p.out[((long long)b * p.Cout + c) * hw + pin] = (half_t)vv;
-                            else p.out[gp * p.ldo + c] = (half_t)vv;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (p.gn_part) {
-        if (outp) {
-            float* dst = ob[0] >= 0 ? p.gn_part + ((long long)ob[0] * p.bpi + (bm - ob[0] * p.bpi)) * p.gn_G * 4 : nullptr;
-            dsc_gn::gn_tile_partials(gs, gq, reinterpret_cast<float*>(smem) + BM * kEpiStride, n0, p.gn_cpg, p.gn_G, dst);
-        } else {
-            dsc_gn::gn_tile_partials_barriers();
-        }
-    }
-}
-
 // out = sum over splits (in split order) + bias + residual, one fp16 rounding
 __global__ __launch_bounds__(256) void conv3x3_reduce(ConvParams p) {
     // (32-bit indices - the entry point bounds pixels x channels below 2^30 - and the division by the vectors per pixel as a
@@ -916,9 +507,6 @@ int tile_width(int H, int W) {
 //   fixed     5 (launch, prologue, epilogue)
 //   split     4 (reduce launch) + the fp32 partials written and read back: S * M * N * 8 bytes at ~3 TB/s
 // e.g. 640->640 @32x32: S=1 26.5 (S=2 30.0); 1280->1280 @16x16: S=5 27 (S=1 46); 1280->1280 @8x8: S=10 17 (S=20 22)
-int g_conv_ring9_always = 0;       // dsc_debug_set_conv_ring(800 / 801): grids of <= 256 workgroups take the nine-stage ring under the latency profile only / under both
-int g_conv_gb = 1;                 // dsc_debug_set_conv_ring(600 / 601 / 602): the K-split kernel's nine-stage form with one barrier per tap / per filter row / per filter row + four loader waves
-int g_conv_k2 = 0;                 // dsc_debug_set_conv_ring(500 / 501 / 502): K-split eight-wave kernel never (default: measured, no gain) / for grids of <= 256 workgroups / always
 int g_conv_loaders = 1;            // dsc_debug_set_conv_ring(400 / 401 / 402): nine-stage kernels without loader waves / by rule / always
 int g_conv_order = -1;             // dsc_debug_set_conv_ring(300 / 301): pixel tiles / channel blocks fastest within an XCD (-1: by shape)
 // us per step the model charges a grid of <= 256 workgroups (dsc_debug_set_conv_ring(200 + hundredths)).  Chosen on images/s,
@@ -967,10 +555,7 @@ int plan(int B, int H, int W, int Cin, int Cout, int splits, ConvParams* p) {
 extern "C" void dsc_debug_set_conv_stamps(void* device_buffer) { g_conv_stamps = static_cast<long long*>(device_buffer); }
 
 extern "C" void dsc_debug_set_conv_ring(int stages) {
-    if (stages >= 800) g_conv_ring9_always = stages - 800;
-    else if (stages >= 600) g_conv_gb = stages - 600;
-    else if (stages >= 500) g_conv_k2 = stages - 500;
-    else if (stages >= 400) g_conv_loaders = stages - 400;
+    if (stages >= 400) g_conv_loaders = stages - 400;
     else if (stages >= 300) g_conv_order = stages - 300;
     else if (stages >= 200) g_conv_small_step = (stages - 200) / 100.0;
     else g_conv_ring = stages;
@@ -1078,11 +663,6 @@ int conv_impl(const void* x, const void* w, const void* bias, const void* residu
                              reinterpret_cast<const void*>(&conv3x3_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9>),
                              reinterpret_cast<const void*>(&conv3x3_kernel<16, 9, 4>), reinterpret_cast<const void*>(&conv3x3_kernel<8, 9, 4>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        const void* fns2[] = {reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 3>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 3>),
-                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9>),
-                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9, 1>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9, 1>),
-                              reinterpret_cast<const void*>(&conv3x3_k2_kernel<16, 9, 1, 4>), reinterpret_cast<const void*>(&conv3x3_k2_kernel<8, 9, 1, 4>)};
-        for (const void* f : fns2) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int total = p.mt * p.nt * p.splits;
@@ -1095,28 +675,12 @@ int conv_impl(const void* x, const void* w, const void* bias, const void* residu
     int ring = g_conv_ring;
     // ... and only while this stream owns the chip: with a second generation in flight the whole-LDS workgroups keep the other
     // stream's kernels off their CUs (dsc_set_tuning_profile)
-    if (ring != 3 && ring != 9) ring = (total <= 256 && (g_dsc_tuning_profile == DSC_TUNE_LATENCY || g_conv_ring9_always)) ? 9 : 3;
+    if (ring != 3 && ring != 9) ring = (total <= 256 && g_dsc_tuning_profile == DSC_TUNE_LATENCY) ? 9 : 3;
     // the nine-stage ring has the CU to itself anyway.  In the step: 16-wide tiles 29.2 -> 25.0 us (160 workgroups), 21.2 ->
     // 19.5 (64); the 8-wide kernel (8x8 level, two halo parities, 12 spilled registers at the 256 cap) 15.0 -> 16.0: not used
     const bool loaders = ring == 9 && (g_conv_loaders == 2 || (g_conv_loaders == 1 && tw == 16));
     const dim3 block8(T + 256);
-    // K-split eight-wave form for the grids that leave a workgroup alone on its CU (chosen by grid size only: the two profiles
-    // differ in ring depth, not in arithmetic)
-    const bool k2 = g_conv_k2 == 2 || (g_conv_k2 == 1 && total <= 256);
-    if (k2) {
-        const dim3 block2(T2);
-        if (tw == 16) {
-            if (ring == 9 && g_conv_gb == 2) DSC_LAUNCH((conv3x3_k2_kernel<16, 9, 1, 4>), grid, dim3(T2 + 256), (size_t)lds_bytes(9), st, p);
-            else if (ring == 9 && g_conv_gb) DSC_LAUNCH((conv3x3_k2_kernel<16, 9, 1>), grid, block2, (size_t)lds_bytes(9), st, p);
-            else if (ring == 9) DSC_LAUNCH((conv3x3_k2_kernel<16, 9>), grid, block2, (size_t)lds_bytes(9), st, p);
-            else DSC_LAUNCH((conv3x3_k2_kernel<16, 3>), grid, block2, (size_t)lds_bytes(3), st, p);
-        } else {
-            if (ring == 9 && g_conv_gb == 2) DSC_LAUNCH((conv3x3_k2_kernel<8, 9, 1, 4>), grid, dim3(T2 + 256), (size_t)lds_bytes(9), st, p);
-            else if (ring == 9 && g_conv_gb) DSC_LAUNCH((conv3x3_k2_kernel<8, 9, 1>), grid, block2, (size_t)lds_bytes(9), st, p);
-            else if (ring == 9) DSC_LAUNCH((conv3x3_k2_kernel<8, 9>), grid, block2, (size_t)lds_bytes(9), st, p);
-            else DSC_LAUNCH((conv3x3_k2_kernel<8, 3>), grid, block2, (size_t)lds_bytes(3), st, p);
-        }
-    } else if (tw == 16) {
+    if (tw == 16) {
         if (loaders) DSC_LAUNCH((conv3x3_kernel<16, 9, 4>), grid, block8, (size_t)lds_bytes(9), st, p);
         else if (ring == 9) DSC_LAUNCH((conv3x3_kernel<16, 9>), grid, block, (size_t)lds_bytes(9), st, p);
         else DSC_LAUNCH((conv3x3_kernel<16, 3>), grid, block, (size_t)lds_bytes(3), st, p);

@@ -303,48 +303,6 @@ def test_conv3x3_kernel(ops, B, Cin, Cout, H, W, splits):
     assert torch.all((oi - ri).abs() <= 1e-3 * ri.abs() + 1e-6)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,splits", [
-    (2, 320, 320, 64, 64, 0), (2, 640, 640, 32, 32, 0), (2, 1280, 1280, 16, 16, 0), (2, 1280, 1280, 8, 8, 0), (2, 192, 64, 24, 48, 3),
-    (2, 1280, 1280, 12, 12, 0), (1, 64, 64, 5, 7, 0), (3, 64, 128, 9, 30, 0), (16, 320, 320, 64, 64, 0), (1, 64, 64, 1, 1, 0)])
-def test_conv3x3_k_split_eight_wave_form(ops, B, Cin, Cout, H, W, splits):
-    """round 4: the K-split form of the convolution (eight computing waves, two per SIMD: waves 0-3 the first 32 input channels of
-    every (slice, tap) step, waves 4-7 the last 32, the halves added in the fp32 stage of the epilogue) FORCED for every grid size
-    and ring depth, against the fp32 convolution - bias / residual, ragged sides, 8- and 16-wide tiles, split slices - and against
-    the four-wave form (same tile, other summation order: equal to fp16 rounding, not to the bit); bit-reproducible; ring depth 3
-    and 9 give equal bytes."""
-    from diffusionspatialcontrol_amd import _lib
-    lib = _lib.load_library()
-    g = torch.Generator().manual_seed(B * 5 + Cin + Cout + H + W)
-    cl = torch.channels_last
-    x = torch.randn(B, Cin, H, W, generator=g).half().cuda().contiguous(memory_format=cl)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).half().cuda().contiguous(memory_format=cl)
-    b = (torch.randn(Cout, generator=g) * 0.2).half().cuda()
-    r = torch.randn(B, Cout, H, W, generator=g).half().cuda().contiguous(memory_format=cl)
-    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + r.float()
-    try:
-        lib.dsc_debug_set_conv_ring(500)
-        four = ops.conv3x3(x, w, b, residual=r, splits=splits)
-        lib.dsc_debug_set_conv_ring(502)
-        outs = {}
-        for ring in (3, 9):
-            lib.dsc_debug_set_conv_ring(ring)
-            outs[ring] = ops.conv3x3(x, w, b, residual=r, splits=splits)
-            assert torch.equal(outs[ring], ops.conv3x3(x, w, b, residual=r, splits=splits))
-        lib.dsc_debug_set_conv_ring(600)                          # nine stages, one barrier per tap (601, the default: per filter row)
-        outs["per tap"] = ops.conv3x3(x, w, b, residual=r, splits=splits)
-        lib.dsc_debug_set_conv_ring(602)                          # ... per filter row with four DMA-only loader waves
-        outs["loaders"] = ops.conv3x3(x, w, b, residual=r, splits=splits)
-        assert torch.equal(outs["loaders"], ops.conv3x3(x, w, b, residual=r, splits=splits))
-    finally:
-        lib.dsc_debug_set_conv_ring(601)
-        lib.dsc_debug_set_conv_ring(0)
-        lib.dsc_debug_set_conv_ring(500 + int(os.environ.get("DSC_CONV_K2", "0")))
-    assert torch.equal(outs[3], outs[9]) and torch.equal(outs["per tap"], outs[9]) and torch.equal(outs["loaders"], outs[9])
-    for o in (four, outs[3]):
-        assert torch.all((o.float() - ref).abs() <= 1.5e-3 * ref.abs() + 2e-3), (o.float() - ref).abs().max().item()
-    assert (four.float() - outs[3].float()).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
-
-
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 1280, 1280, 16, 16), (2, 1280, 1280, 8, 8), (2, 640, 640, 32, 32), (1, 64, 128, 16, 24)])
 def test_conv3x3_and_gemm_profiles_give_equal_bytes(ops, B, Cin, Cout, H, W):
     """dsc_set_tuning_profile: the latency rules (nine-stage convolution ring for small grids, GEMM loader waves) and the

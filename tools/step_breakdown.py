@@ -13,7 +13,7 @@ import csv
 import re
 import sys
 
-FAMILIES = [("conv3x3_kernel", "conv3x3"), ("conv3x3_k2_kernel", "conv3x3"), ("conv3x3_reduce", "conv_reduce"), ("gemm_splitk_reduce", "gemm_reduce"), ("gemm_tn", "gemm_tn"), ("self_attn", "self_attn"),
+FAMILIES = [("conv3x3_kernel", "conv3x3"), ("conv3x3_reduce", "conv_reduce"), ("gemm_splitk_reduce", "gemm_reduce"), ("gemm_tn", "gemm_tn"), ("self_attn", "self_attn"),
             ("gn_nhwc", "groupnorm"), ("xp_", "xattn"), ("CatArray", "cat"), ("add_ln", "add_ln")]
 
 
