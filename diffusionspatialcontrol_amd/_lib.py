@@ -71,12 +71,6 @@ _SIGNATURES = {
     "dsc_get_tuning_profile": (ctypes.c_int, []),
     "dsc_linear_lt_stats": (None, [_vp]),
     "dsc_has_library_gemm": (ctypes.c_int, []),
-    "dsc_xattn_gram_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
-    "dsc_xattn_gram_pack": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int] * 4 + [_i64p, ctypes.c_int, _vp]),
-    "dsc_linear_q_gram_parts": (ctypes.c_int, [ctypes.c_int64] + [ctypes.c_int] * 6),
-    "dsc_linear_q_gram_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
-                                             _vp, ctypes.c_int, _vp, ctypes.c_float, _vp, _vp, _vp] + [ctypes.c_int] * 4 +
-                              [ctypes.c_float, _vp, ctypes.c_int, _vp]),
     "dsc_add_bias_residual": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_linear_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                        [ctypes.c_int, ctypes.c_int, _vp]),

@@ -71,10 +71,6 @@ struct GemmParams {
     // that has a row per CFG branch): row m adds residual row m % res_rows; res_rows % BM == 0, so a row tile lies in one copy
     int res_rows; FastDiv fd_res;
     long long* stamps;           // diagnostics (dsc_debug_set_gemm_stamps): 8 x int64 per workgroup, NULL in normal calls
-    // dsc_linear_q_gram_f16 (NT = 3 tiles: 64 rows x 160 valid columns = whole heads): the cross-attention's to_q projection whose
-    // epilogue also emits the (sum a, sum a^2) partial pairs of the scores a = scale q.k^T its rows will produce - see gram_epilogue
-    const half_t* gram; const float* gscale; const float* ksum; double* gram_part;
-    int g_H, g_d, g_L, g_nimg, g_reps, g_JP, g_KP, g_npart; float g_scale;
     int nt_store;                // GEGLU: the hidden tensor (written once, read once by the next GEMM) with non-temporal stores
 };
 
@@ -110,149 +106,6 @@ __device__ __forceinline__ void row_stats(const GemmParams& p, long long m, floa
     rs = rsqrtf(var + p.ln_eps);
 }
 
-// Epilogue of the NT = 3 form (dsc_linear_q_gram_f16): the cross-attention's query projection, whose column tile holds WHOLE
-// heads (160 valid columns = 4 / 2 / 1 heads of 40 / 80 / 160 channels), so that the statistics of the scores its rows will
-// produce against the text keys can be taken here instead of by a launch of their own (xp_stats: 5.2 us in the step, the
-// region cross-attention op's std pass).  For a = scale q.k over the S keys of a head:
-//     sum_s a = scale q . (sum_s k_s)            sum_s a^2 = scale^2 q^T (K^T K) q
-// `gram` holds K^T K per (text row, head) in fp16, scaled by gscale and zero-padded to MFMA tiles (ops.xattn_gram_pack: once per
-// generation), `ksum` the key sums.  The tile's fp16 q values - the values the score kernel will read - go to LDS as an MFMA
-// operand; per (32 rows, head, 32 Gram rows): T = G q^T on v_mfma_f32_32x32x16_f16, then sum_{j'} T[j'][row] q[row][j'].  One
-// (sum a, sum a^2) fp64 pair per workgroup and text row, slot order fixed -> reproducible; the forward kernel adds the pairs of
-// its std group exactly as it adds xp_stats' (DSC_FLAG_EXT_STATS).  g_reps = 2: the rows were computed once for both CFG halves
-// (shared prefix) and meet two text rows.
-constexpr int kGramES = 196;                                  // fp32 stage row stride (192 + 4)
-constexpr int kGramQS = 192;                                  // fp16 q tile row stride (160 valid + 32 zero columns)
-constexpr int kGramGMax = 12;                                 // 16-byte pieces of the tile's Gram images per thread (<= 48 KiB)
-constexpr int kGramEpiBytes = 64 * kGramES * 4 + 64 * kGramQS * 2 + 160 * 2 + 160 * 4 + 2 * 160 * 4 + 128 * 4 + 16 * 8;
-__device__ __forceinline__ void gram_epilogue(const GemmParams& p, const f16x_t (&acc)[3], char* smem, int m0, int n0, int bn, int nb,
-                                              float ln_mu, float ln_rs, int wave, int lane) {
-    const int r = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    float* stage = reinterpret_cast<float*>(smem);                               // [64][196]; later the tile's Gram images
-    half_t* qt = reinterpret_cast<half_t*>(smem + 64 * kGramES * 4);             // [64][192]
-    half_t* cbias = qt + 64 * kGramQS;                                           // [160]
-    float* ccvec = reinterpret_cast<float*>(cbias + 160);                        // [160]
-    float* cks = ccvec + 160;                                                    // [2][160] key sums of the tile's columns
-    float* rowst = cks + 320;                                                    // [64][2]
-    double* red = reinterpret_cast<double*>(rowst + 128);                        // [4 waves][2 reps][2]
-    const int bq = m0 / p.g_L;                                                   // this tile's batch row of q (L % 64 == 0)
-    const int d = p.g_d, hpt = 160 / d, JT = p.g_JP >> 5, KS = p.g_KP >> 4;
-    const int h0 = n0 / d;
-    __syncthreads();                                                             // (1) all MFMA operand reads of the K loop done
-    // the tile's Gram images (hpt heads per text row, contiguous in `gram`) into registers now - their latency rides under the
-    // staging and the output pass - and into LDS once the fp32 stage is free
-    const int gpieces = (hpt * p.g_JP * p.g_KP) >> 3;                            // 16-byte pieces per text row
-    h8_t gpre[kGramGMax];
-#pragma unroll
-    for (int i = 0; i < kGramGMax; ++i) {
-        const int pc = threadIdx.x + i * T;                                      // piece of (rep, image)
-        gpre[i] = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        if (pc < gpieces * p.g_reps) {
-            const int rep = pc >= gpieces ? 1 : 0, q8 = pc - rep * gpieces;
-            const int bt = p.g_reps > 1 ? bq + rep * p.g_nimg : bq;
-            gpre[i] = *reinterpret_cast<const h8_t*>(p.gram + ((long long)bt * p.g_H + h0) * p.g_JP * p.g_KP + (long long)q8 * 8);
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f4x_t v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
-            *reinterpret_cast<f4x_t*>(stage + (wm * 32 + r) * kGramES + wn * 96 + nt * 32 + 8 * g + 4 * hh) = v;
-        }
-    if (threadIdx.x < 160) {
-        cbias[threadIdx.x] = p.bias ? p.bias[n0 + threadIdx.x] : (half_t)0.f;
-        ccvec[threadIdx.x] = p.ln_in ? p.ln_c[n0 + threadIdx.x] : 0.f;
-        cks[threadIdx.x] = p.ksum[(long long)(p.g_reps > 1 ? bq : bq) * p.N + n0 + threadIdx.x];
-        cks[160 + threadIdx.x] = p.g_reps > 1 ? p.ksum[(long long)(bq + p.g_nimg) * p.N + n0 + threadIdx.x] : 0.f;
-    }
-    if (threadIdx.x < 64) { rowst[2 * threadIdx.x] = ln_mu; rowst[2 * threadIdx.x + 1] = ln_rs; }
-    {                                                                            // zero columns 160..191 of the q tile
-        const int row = threadIdx.x >> 2, ch = threadIdx.x & 3;
-        *reinterpret_cast<h8_t*>(qt + row * kGramQS + 160 + ch * 8) = h8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    __syncthreads();                                                             // (2)
-    float sa[2] = {0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {                                                // 64 rows x 20 chunks of 8 columns
-        const int idx = threadIdx.x + c * T, row = idx / 20, ch = idx - row * 20;
-        const float mu = rowst[2 * row], rs = rowst[2 * row + 1];
-        const float* sp = stage + row * kGramES + ch * 8;
-        h8_t o;
-        float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float a = sp[j];
-            if (p.ln_in) a = rs * (a - mu * ccvec[ch * 8 + j]);
-            o[j] = (half_t)(a + (float)cbias[ch * 8 + j]);
-            t0 += (float)o[j] * cks[ch * 8 + j];
-            t1 += (float)o[j] * cks[160 + ch * 8 + j];
-        }
-        *reinterpret_cast<h8_t*>(qt + row * kGramQS + ch * 8) = o;
-        if (m0 + row < p.M) {
-            *reinterpret_cast<h8_t*>(p.out + (long long)(m0 + row) * p.ldo + n0 + ch * 8) = o;
-            sa[0] += t0; sa[1] += t1;
-        }
-    }
-    __syncthreads();                                                             // (3) the q tile is complete, the stage is free
-    half_t* gl = reinterpret_cast<half_t*>(smem);                                // [reps][hpt][JP][KP]
-#pragma unroll
-    for (int i = 0; i < kGramGMax; ++i) {
-        const int pc = threadIdx.x + i * T;
-        if (pc < gpieces * p.g_reps) *reinterpret_cast<h8_t*>(gl + (long long)pc * 8) = gpre[i];
-    }
-    __syncthreads();                                                             // (4)
-    // ---- T = G q^T per (32-row block, head, 32 Gram rows); units dealt round-robin over the four waves
-    const int units = 2 * hpt * JT;
-    float t2[2] = {0.f, 0.f};
-#pragma unroll 1
-    for (int u = wave; u < units; u += 4) {
-        const int rb = u & 1, rest = u >> 1, hd = rest / JT, jt = rest - hd * JT;
-        const half_t* qrow = qt + (rb * 32 + r) * kGramQS + hd * d;
-        h4_t qv[4];
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) qv[g4] = *reinterpret_cast<const h4_t*>(qrow + jt * 32 + 8 * g4 + 4 * hh);
-#pragma unroll 1
-        for (int rep = 0; rep < p.g_reps; ++rep) {
-            const int bt = p.g_reps > 1 ? bq + rep * p.g_nimg : bq;
-            const half_t* G = gl + ((rep * hpt + hd) * p.g_JP + jt * 32 + r) * p.g_KP + 8 * hh;
-            f16x_t tt;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tt[i] = 0.f;
-#pragma unroll 5
-            for (int ks = 0; ks < KS; ++ks)
-                tt = mfma_32x32x16(*reinterpret_cast<const h8_t*>(G + 16 * ks), *reinterpret_cast<const h8_t*>(qrow + 16 * ks + 8 * hh), tt);
-            float part = 0.f;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) part += tt[4 * g4 + j] * (float)qv[g4][j];
-            if (m0 + rb * 32 + r < p.M) t2[rep] += part * p.gscale[bt * p.g_H + h0 + hd];
-        }
-    }
-    // ---- one (sum a, sum a^2) pair per workgroup and text row: lanes -> wave (fp64 butterfly) -> the four waves in order
-#pragma unroll 1
-    for (int rep = 0; rep < p.g_reps; ++rep) {
-        const double s1 = wave_sum_f64((double)sa[rep]), s2 = wave_sum_f64((double)t2[rep]);
-        if (lane == 0) { red[(wave * 2 + rep) * 2] = s1; red[(wave * 2 + rep) * 2 + 1] = s2; }
-    }
-    __syncthreads();                                                             // (5)
-    if ((int)threadIdx.x < p.g_reps) {
-        const int rep = threadIdx.x;
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { s1 += red[(w * 2 + rep) * 2]; s2 += red[(w * 2 + rep) * 2 + 1]; }
-        const int rt = (m0 - bq * p.g_L) >> 6;
-        const int tpb = (p.g_L >> 6) * nb;
-        const int g = bq % p.g_nimg;
-        const int rep_index = p.g_reps > 1 ? rep : bq / p.g_nimg;
-        double* dst = p.gram_part + ((long long)g * p.g_npart + rep_index * tpb + rt * nb + bn) * 2;
-        dst[0] = s1 * (double)p.g_scale;
-        dst[1] = s2 * (double)p.g_scale * (double)p.g_scale;
-    }
-}
-
 // GEGLU: the workgroup's 64 weight rows are 32 "hidden" rows n0h.. and the 32 matching "gate" rows N/2 + n0h..
 // BM = 128 token rows per workgroup, or 64 for GEMMs with few token rows (the 16x16 level: M = 512 gives 80 workgroups of
 // 128 rows on 256 CUs, each walking 20 K tiles alone; 64-row tiles double the workgroups and take 4 instead of 6 DMA pieces and
@@ -267,8 +120,7 @@ __device__ __forceinline__ void gram_epilogue(const GemmParams& p, const f16x_t 
 template <bool GEGLU, int STAGES, int BM, int NLOAD, int NT = 1>
 __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))) void gemm_tn_f16(GemmParams p) {
     static_assert(BM == 128 || (BM == 64 && !GEGLU), "tile heights");
-    static_assert(NT == 1 || (NT == 2 && BM == 128 && NLOAD == 0) || (NT == 3 && BM == 64 && !GEGLU), "tile widths");
-    constexpr int NVALID = NT == 3 ? 160 : BN * NT;          // output columns a tile owns (NT = 3: 160 of its 192 = whole heads)
+    static_assert(NT == 1 || (NT == 2 && BM == 128 && NLOAD == 0), "tile widths");
     constexpr bool LOADER = NLOAD > 0;
     constexpr int NISS = LOADER ? NLOAD : 4;                 // waves that issue DMA
     constexpr int MT = BM / 64;                              // 32-row fragments per wave
@@ -281,7 +133,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;                 // wave grid 2 (tokens) x 2 (channels): (BM/2) x 32 NT per wave
-    const int nb = p.N / NVALID;                             // column blocks (GEGLU: 32 NT output columns per block)
+    const int nb = p.N / BNT;                                // column blocks (GEGLU: 32 NT output columns per block)
     // XCD-aware order (as in conv3x3.hip): workgroup i runs on XCD i % 8, so consecutive VIRTUAL ids - the column blocks of
     // one activation panel - go to one XCD and that panel is fetched into one L2 instead of eight
     // Each XCD has its own L2 and workgroup i runs on XCD i % 8.  xcd_remap (activation-heavy shapes, M >= 2 N): consecutive
@@ -305,7 +157,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     }
     const int bm = fdiv(bid, p.fd_nb), bn = bid - bm * nb;   // consecutive workgroups share the activation panel
     const int m0 = bm * BM;
-    const int n0 = GEGLU ? bn * (32 * NT) : bn * NVALID;
+    const int n0 = GEGLU ? bn * (32 * NT) : bn * BNT;
     const int Nh = p.N / 2;
 
     const int iw = LOADER ? wave - 4 : wave;                 // index among the issuing waves
@@ -358,10 +210,6 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                 __builtin_amdgcn_s_barrier();                // publishes tile kt; every computing wave has left tile kt-1's stage
                 if (kt + STAGES - 1 < nk) issue(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
             }
-            if constexpr (NT == 3) {                         // gram_epilogue's five workgroup barriers
-                __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
-                return;
-            }
             __syncthreads();                                 // the epilogue's two workgroup barriers
             __syncthreads();
             if (p.gn_part) dsc_gn::gn_tile_partials_barriers();
@@ -383,11 +231,11 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
     f4x_t cpre[GEGLU ? 4 : 2];
 #pragma unroll
     for (int i = 0; i < (GEGLU ? 4 : 2); ++i) cpre[i] = f4x_t{0.f, 0.f, 0.f, 0.f};
-    if (NT != 3 && p.bias) {
+    if (p.bias) {
         bpre0 = *reinterpret_cast<const h8_t*>(p.bias + n0 + ech * 8);
         if (GEGLU) bpre1 = *reinterpret_cast<const h8_t*>(p.bias + Nh + n0 + ech * 8);
     }
-    if (NT != 3 && p.ln_in) {
+    if (p.ln_in) {
         cpre[0] = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ech * 8);
         cpre[1] = *reinterpret_cast<const f4x_t*>(p.ln_c + n0 + ech * 8 + 4);
         if (GEGLU) {
@@ -417,10 +265,6 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_32x32x16(wf[nt], xf, acc[mt][nt]);
             }
         }
-    }
-    if constexpr (NT == 3) {
-        gram_epilogue(p, acc[0], smem, m0, n0, bn, nb, ln_mu, ln_rs, wave, lane);
-        return;
     }
     // residual rows of this thread's four output chunks: issued before the staging pass so that their latency (HBM /
     // Infinity Cache: the residual stream was written by an earlier kernel) hides under it
@@ -811,65 +655,6 @@ int gemm_tile_rows(int64_t M, int N, bool geglu) {
     return bm;
 }
 }  // namespace
-
-// (sum a, sum a^2) partial pairs per std group that dsc_linear_q_gram_f16 writes, 0 when the shape is not covered: 64-row tiles,
-// 160-column tiles of whole heads, the rows of one text row (L of them) a whole number of tiles
-extern "C" int dsc_linear_q_gram_parts(int64_t M, int N, int K, int heads, int L, int n_text_rows, int n_std_groups) {
-    if (M <= 0 || N <= 0 || K <= 0 || heads <= 0 || L <= 0 || n_text_rows <= 0 || n_std_groups <= 0) return 0;
-    if (N % 160 != 0 || N % heads != 0 || K % BK != 0 || L % 64 != 0 || M % L != 0 || M > (1ll << 30)) return 0;
-    const int d = N / heads;
-    if (d % 8 != 0 || 160 % d != 0) return 0;
-    const int64_t bq = M / L;
-    if (n_text_rows % bq != 0) return 0;
-    const int reps = (int)(n_text_rows / bq);
-    if (reps == 1 ? (n_text_rows % n_std_groups != 0) : (reps != 2 || bq != n_std_groups)) return 0;
-    // the tile's Gram images (160 / d heads per text row) are staged through the epilogue's fp32 stage: 48 KiB
-    if ((long long)reps * (160 / d) * ((d + 31) / 32 * 32) * ((d + 15) / 16 * 16) * 2 > (long long)kGramGMax * T * 16) return 0;
-    return (n_text_rows / n_std_groups) * (L / 64) * (N / 160);
-}
-
-extern "C" int dsc_linear_q_gram_f16(const void* x, const void* w, const void* bias, void* out, int64_t M, int N, int K,
-                                     int64_t ldx, int64_t ldo, const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps,
-                                     const void* gram, const float* gscale, const float* ksum, int heads, int L,
-                                     int n_text_rows, int n_std_groups, float scale, double* parts, int dtype, void* stream) {
-    if (!x || !w || !out || !gram || !gscale || !ksum || !parts) return DSC_ERR_BAD_ARG;
-    if ((ln_in && (!ln_cvec || ln_nb <= 0))) return DSC_ERR_BAD_ARG;
-    if (dtype != DSC_F16) return DSC_ERR_UNSUPPORTED;
-    const int npart = dsc_linear_q_gram_parts(M, N, K, heads, L, n_text_rows, n_std_groups);
-    if (!npart) return DSC_ERR_UNSUPPORTED;
-    if (ldx % 8 != 0 || ldo % 8 != 0 || !al16(x) || !al16(w) || !al16(out) || (bias && !al16(bias)) || !al16(gram) || !al16(ksum) ||
-        (ln_in && !al16(ln_cvec)) || (reinterpret_cast<uintptr_t>(parts) & 7))
-        return DSC_ERR_UNSUPPORTED;
-    GemmParams p{};
-    p.x = static_cast<const half_t*>(x); p.w = static_cast<const half_t*>(w); p.bias = static_cast<const half_t*>(bias);
-    p.out = static_cast<half_t*>(out);
-    p.M = (int)M; p.N = N; p.K = K; p.ldx = ldx; p.ldo = ldo;
-    p.ln_in = ln_in; p.ln_c = ln_cvec; p.ln_nb = ln_nb; p.ln_inv_c = 1.f / (float)K; p.ln_eps = ln_eps;
-    p.gram = static_cast<const half_t*>(gram); p.gscale = gscale; p.ksum = ksum; p.gram_part = parts;
-    p.g_H = heads; p.g_d = N / heads; p.g_L = L; p.g_nimg = n_std_groups;
-    p.g_reps = (int)(n_text_rows / (M / L));
-    p.g_JP = (p.g_d + 31) / 32 * 32; p.g_KP = (p.g_d + 15) / 16 * 16; p.g_npart = npart;
-    p.g_scale = scale > 0.f ? scale : 1.0f / sqrtf((float)p.g_d);
-    const int mb = (int)((M + 63) / 64), nb = N / 160;
-    p.xcd_remap = M >= 2ll * N ? 1 : 0;
-    p.tiles = mb * nb; p.splits = 1; p.total = p.tiles;
-    p.fd_nb = make_fastdiv(nb, p.total); p.fd_tiles = make_fastdiv(p.tiles, p.total);
-    p.fd_res = make_fastdiv(1, M);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 0, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    size_t lds = (size_t)3 * stage_halves(64, 3) * sizeof(half_t);
-    if (lds < (size_t)kGramEpiBytes) lds = kGramEpiBytes;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(p.xcd_remap ? ((p.total + 7) / 8) * 8 : p.total);
-    // loader waves under the latency profile, as for the other 64-row tiles (equal bytes either way)
-    if (g_dsc_tuning_profile == DSC_TUNE_LATENCY) DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 4, 3>), grid, dim3(T + 256), lds, st, p);
-    else DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 0, 3>), grid, dim3(T), lds, st, p);
-    return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
-}
 
 // partial rows per image of dsc_linear_gn_f16 (row tiles per image), 0 when the shape is not covered
 extern "C" int dsc_linear_gn_rows(int64_t M, int N, int K, int rows_per_image, int groups) {

@@ -724,21 +724,12 @@ extern "C" int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv,
     p.std_out = static_cast<float*>(g_debug_stamps);
     pp.img = static_cast<const half_t*>(packed_kv);
     pp.ids = region_ids; pp.rows = region_rows; pp.NU = has_bias ? n_rows : 0;
-    const bool ext_stats = has_bias && (flags & DSC_FLAG_EXT_STATS) != 0;
-    if (ext_stats) {
-        // the (sum a, sum a^2) partial pairs come from another kernel (dsc_linear_q_gram_f16): [n_std_groups][npart][2]
-        if ((flags & DSC_FLAG_REF_FP16_ROUNDING) || nkc > 1) return DSC_ERR_UNSUPPORTED;
-        const size_t per = (size_t)n_std_groups * 2 * sizeof(double);
-        if (!workspace || workspace_bytes < per || workspace_bytes % per != 0 || (reinterpret_cast<uintptr_t>(workspace) & 7))
-            return DSC_ERR_WORKSPACE;
-        p.npart = (int)(workspace_bytes / per);
-        p.partials = static_cast<double*>(workspace);
-    } else if (has_bias) {
+    if (has_bias) {
         const size_t need = (size_t)n_std_groups * p.npart * 2 * sizeof(double);
         if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;
         p.partials = static_cast<double*>(workspace);
     }
-    const bool need_stats = has_bias && !ext_stats && !(flags & DSC_FLAG_REUSE_STATS);
+    const bool need_stats = has_bias && !(flags & DSC_FLAG_REUSE_STATS);
     if (nkc > 1) return dispatch_packed_long(pick_nk(d), pp, nkc, need_stats, static_cast<hipStream_t>(stream));
     return dispatch_packed(pick_nk(d), (flags & DSC_FLAG_REF_FP16_ROUNDING) != 0, pp, need_stats,
                            static_cast<hipStream_t>(stream));

@@ -187,7 +187,7 @@ def _region_attention_masked(q, k, v, w, sigma, weight_func, layout, n_std_group
 
 
 def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scale=None, ref16=False, packed_kv=None,
-                      comp=None, mask=None, ext_stats=None):
+                      comp=None, mask=None):
     """comp: the caller's (ids, rows) of `w`, None = compress `w` here (cached per tensor version), False = `w` is a static
     buffer whose CONTENTS change between replays of a captured step: read it densely, derive nothing from its values."""
     S = k.shape[2 if layout == "bhld" else 1]
@@ -212,8 +212,7 @@ def _region_attention(q, k, v, w, sigma, weight_func, layout, n_std_groups, scal
                 comp = compressed_table(w, q.device)
             if comp is not None:                 # prepared operands: packed text K/V + row-id region table
                 return ops.region_xattn_packed(q, packed_kv, k.shape[1], comp, _sigma_arg(sigma, q.device),
-                                               n_std_groups=n_std_groups, scale=scale, ref_fp16_rounding=ref16,
-                                               ext_stats=None if ref16 else ext_stats)
+                                               n_std_groups=n_std_groups, scale=scale, ref_fp16_rounding=ref16)
         w_dev = resident_table(w, q.device)
         return ops.region_xattn(q, k, v, w_dev, _sigma_arg(sigma, q.device), layout=layout, n_std_groups=n_std_groups,
                                 scale=scale, ref_fp16_rounding=ref16)
@@ -334,44 +333,20 @@ class _RegionProcessor:
                 q4, k4, v4 = (qkv[..., i * C:(i + 1) * C].unflatten(-1, (H, d)) for i in range(3))
             S = L
         else:
+            if _ln_fold is not None:
+                w2, b2, cvec = _ln_fold.folded(attn, "q", attn.to_q.weight, attn.to_q.bias)
+                query = ops.linear_ln(hidden_states, w2, b2, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
+            else:
+                query = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias) if type(attn.to_q) is nn.Linear \
+                    else attn.to_q(hidden_states)
             if is_self:
                 encoder_hidden_states = hidden_states
             elif attn.norm_cross:
                 encoder_hidden_states = attn.norm_encoder_hidden_states(encoder_hidden_states)
-            cache = None if is_self else getattr(attn, "kv_cache", None)
+            cache = getattr(attn, "kv_cache", None)
             if cache is not None and cache["src"] is not encoder_hidden_states:     # another generation slot's text buffer?
                 cache = next((c for c in getattr(attn, "kv_caches", ()) if c["src"] is encoder_hidden_states), None)
-            if cache is not None and cache["src"] is not encoder_hidden_states:
-                cache = None
-            # The std's partial sums from THIS projection's epilogue (ops.linear_q_gram: sum_s a and sum_s a^2 need of the keys only
-            # their sum and their Gram matrix, packed once per generation) instead of a statistics launch - where the region path
-            # will run the prepared-operand kernels on fp32 scores with the default weight_func and no attention mask
-            xstats = None
-            gram = cache.get("gram") if cache is not None else None
-            if (gram is not None and is_xattn and mask3 is None and not self.ref_fp16_rounding and cache.get("packed") is not None
-                    and hidden_states.dtype == torch.float16 and hidden_states.dim() == 3
-                    and isinstance(region_prompt["region_state"], dict)
-                    and (region_prompt["weight_func"] is None or weight_func_is_default(region_prompt["weight_func"]))
-                    and isinstance(region_prompt.get("compressed"), dict) and img_sequence_length in region_prompt["compressed"]
-                    and not (self.honours_attn_scale and attn.scale is None)):
-                Bq_, L_, K_ = hidden_states.shape
-                n_txt = cache["k"].shape[0]
-                groups_ = region_prompt.get("n_std_groups", self.n_std_groups)
-                if Bq_ * L_ >= ops.XATTN_GRAM_MIN_ROWS and ops.linear_q_gram_parts(Bq_ * L_, attn.to_q.weight.shape[0], K_, H, L_, n_txt, groups_):
-                    sc_ = attn.scale if self.honours_attn_scale else None
-                    if _ln_fold is not None:
-                        w2, b2, cvec = _ln_fold.folded(attn, "q", attn.to_q.weight, attn.to_q.bias)
-                        query, xstats = ops.linear_q_gram(hidden_states, w2, b2, gram, H, n_txt, groups_,
-                                                          ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps), scale=sc_)
-                    elif type(attn.to_q) is nn.Linear:
-                        query, xstats = ops.linear_q_gram(hidden_states, attn.to_q.weight, attn.to_q.bias, gram, H, n_txt, groups_, scale=sc_)
-            if xstats is None and _ln_fold is not None:
-                w2, b2, cvec = _ln_fold.folded(attn, "q", attn.to_q.weight, attn.to_q.bias)
-                query = ops.linear_ln(hidden_states, w2, b2, ln=(_ln_fold.stats, cvec, _ln_fold.norm.eps))
-            elif xstats is None:
-                query = ops.linear(hidden_states, attn.to_q.weight, attn.to_q.bias) if type(attn.to_q) is nn.Linear \
-                    else attn.to_q(hidden_states)
-            if cache is not None:
+            if cache is not None and cache["src"] is encoder_hidden_states:
                 key, value = cache["k"], cache["v"]          # text K/V: once per generation, not once per step
                 packed_kv = cache.get("packed")
             else:
@@ -398,8 +373,7 @@ class _RegionProcessor:
                 # reference raises here - so does this (same exception type)
                 torch.zeros(L, S, dtype=q4.dtype, device=q4.device).add_(mask3.view(B, H, -1, S))
             out = _region_attention(q4, k4, v4, w, region_prompt["sigma"], region_prompt["weight_func"], "blhd",
-                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp, mask=mask3,
-                                    ext_stats=xstats if (comp is not None and comp is not False) else None)
+                                    groups, sc, ref16=self.ref_fp16_rounding, packed_kv=packed_kv, comp=comp, mask=mask3)
         elif mask3 is not None:
             # no region table: plain masked attention (:483-485 / :182-186) - the mask is the forward kernel's final bias when
             # the keys fit it, else the library's SDPA

@@ -1284,12 +1284,6 @@ class StableDiffusionPipeline:
                 if S <= 384 and d % 8 == 0 and d <= 160:          # > 96 keys: one image per 96-key chunk (long prompts)
                     c["packed"] = ops.xattn_kv_pack(c["k"].view(B, S, m.heads, d), c["v"].view(B, S, m.heads, d),
                                                     out=c.get("packed"))
-                # Gram matrix / key sums: what the to_q projection's epilogue needs to emit the std's partial sums itself
-                # (ops.linear_q_gram; rewritten in place like the packed image)
-                if ops.USE_XATTN_GRAM and S <= 96 and d % 8 == 0 and 160 % d == 0 and k.dtype == torch.float16:
-                    c["gram"] = ops.xattn_gram_pack(c["k"].view(B, S, m.heads, d), out=c.get("gram"))
-                else:
-                    c["gram"] = None
 
     def _drop_text_kv(self):
         from .u_net_condition_modify import Attention

@@ -1,7 +1,6 @@
 """Thin torch-tensor wrappers over the C ABI (include/dsc_hip.h).  torch is plumbing here: device memory,
 the current HIP stream and strides; all arithmetic happens in libdsc_hip.so."""
 import ctypes
-import math
 import os
 
 import numpy as np
@@ -13,7 +12,6 @@ FLAG_REF_FP16_ROUNDING = 1
 FLAG_BIAS_IS_FINAL = 2
 FLAG_REUSE_STATS = 4
 FLAG_ROWS_PADDED = 256
-FLAG_EXT_STATS = 512
 REGION_ROW_STRIDE = 100    # region_xattn_packed.hip kBP: the forward kernel's LDS bias-table row stride (floats)
 
 def _stream_ptr(t):
@@ -193,11 +191,9 @@ def pad_region_rows(rows):
 
 
 def region_xattn_packed(q, packed_kv, S, region=None, sigma=1.0, *, n_std_groups=1, scale=None, ref_fp16_rounding=True,
-                        out=None, reuse_stats=False, debug_flags=0, ext_stats=None):
+                        out=None, reuse_stats=False, debug_flags=0):
     """dsc_region_xattn_fwd_packed: q [Bc,L,H,d] view, packed_kv from xattn_kv_pack, region = (ids, rows) from
-    compress_region_table (device tensors; rows optionally through pad_region_rows) or None -> out [Bc,L,H,d] contiguous.
-    ext_stats: fp64 [n_std_groups, npart, 2] (sum a, sum a^2) partial pairs of THIS call's scores computed elsewhere
-    (linear_q_gram: the to_q projection's epilogue) - the statistics launch is skipped (DSC_FLAG_EXT_STATS)."""
+    compress_region_table (device tensors; rows optionally through pad_region_rows) or None -> out [Bc,L,H,d] contiguous."""
     _require_gpu(q, packed_kv)
     lib = _lib.load_library()
     qs, (Bc, H, L, d) = _blhd_strides(q, "blc")
@@ -217,50 +213,12 @@ def region_xattn_packed(q, packed_kv, S, region=None, sigma=1.0, *, n_std_groups
     flags = (FLAG_REF_FP16_ROUNDING if ref_fp16_rounding else 0) | (FLAG_REUSE_STATS if reuse_stats else 0) | debug_flags
     if rows is not None and rows.shape[1] == REGION_ROW_STRIDE and S <= 96:      # pad_region_rows() form ([NU, S] has S <= 96 columns)
         flags |= FLAG_ROWS_PADDED
-    if ext_stats is not None and region is not None:
-        if (ext_stats.dtype != torch.float64 or not ext_stats.is_contiguous() or ext_stats.dim() != 3 or ext_stats.shape[0] != n_std_groups
-                or ext_stats.shape[2] != 2 or ref_fp16_rounding):
-            raise ValueError("region_xattn_packed: ext_stats is fp64 [n_std_groups, npart, 2], fp32-score mode only")
-        flags |= FLAG_EXT_STATS
-        ws = ext_stats.view(-1)
-    else:
-        ws = _workspace(q.device, lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups))
+    ws = _workspace(q.device, lib.dsc_region_xattn_workspace_bytes(Bc, H, L, S, d, n_std_groups))
     rc = lib.dsc_region_xattn_fwd_packed(_p(q), _p(packed_kv), _p(out), _p(ids), _p(rows), nrows, Bc, H, L, S, d, Bw,
                                          n_std_groups, _i64x3(*qs), _i64x3(*os_), sig_host, sig_dev,
                                          float(scale) if scale else 0.0, 0, flags, _p(ws), ws.numel() * 8, _stream_ptr(q))
     _lib.check(rc, "dsc_region_xattn_fwd_packed")
     return out
-
-
-def gram_dims(d):
-    """(JP, KP): rows (multiple of 32) and columns (multiple of 16) of a head's padded Gram image"""
-    return (d + 31) // 32 * 32, (d + 15) // 16 * 16
-
-
-def xattn_gram_pack(k, out=None):
-    """Per (text row, head) the Gram matrix of the keys and their sum - all the statistics pass needs of K once the scores'
-    moments are written as  sum_s a = scale q.(sum_s k_s),  sum_s a^2 = scale^2 q^T (K^T K) q  (a = scale q.k, reference
-    attention_modify.py:90,96): dsc_xattn_gram_pack.  k: [Bt, S, H, d] fp16 view (the values the score kernels multiply).  Returns
-      G16   fp16 [Bt, H, JP, KP]  K^T K / gscale, zero padded to MFMA tiles (gram_dims)
-      gscale fp32 [Bt, H]          max |K^T K| / 1024 per (row, head): fp16 keeps 11 bits of every entry whatever the keys' range
-      ksum  fp32 [Bt, H * d]       sum over the S keys
-    Once per generation (the text is step-invariant), next to xattn_kv_pack; `out` = a previous result to overwrite in place
-    (captured graphs keep reading the same buffers)."""
-    _require_gpu(k)
-    if k.dtype != torch.float16 or k.dim() != 4:
-        raise TypeError("xattn_gram_pack: k is an fp16 [Bt, S, H, d] view")
-    Bt, S, H, d = k.shape
-    JP, KP = gram_dims(d)
-    if out is not None and out[0].shape == (Bt, H, JP, KP):
-        G16, gscale, ksum = out
-    else:
-        G16 = torch.empty((Bt, H, JP, KP), dtype=torch.float16, device=k.device)
-        gscale = torch.empty((Bt, H), dtype=torch.float32, device=k.device)
-        ksum = torch.empty((Bt, H * d), dtype=torch.float32, device=k.device)
-    rc = _lib.load_library().dsc_xattn_gram_pack(_p(k), _p(G16), _p(gscale), _p(ksum), Bt, H, S, d,
-                                                 _i64x3(k.stride(0), k.stride(1), k.stride(2)), 0, _stream_ptr(k))
-    _lib.check(rc, "dsc_xattn_gram_pack")
-    return G16, gscale, ksum
 
 
 def region_xattn_std(q, k, *, layout="bhld", n_std_groups=1, scale=None, ref_fp16_rounding=True, mask=None):
@@ -656,50 +614,6 @@ def linear_ln(x, weight, bias, *, residual=None, geglu=False, ln=None, ln_stats=
     _lib.check(rc, "dsc_linear_ln_f16")
     out = out.reshape(*lead, n_out)
     return (out, stats) if ln_stats else out
-
-
-USE_XATTN_GRAM = os.environ.get("DSC_XATTN_GRAM", "1") != "0"    # the cross-attention std from the to_q projection's epilogue (linear_q_gram)
-XATTN_GRAM_MIN_ROWS = int(os.environ.get("DSC_XATTN_GRAM_MIN_ROWS", "2048"))   # ... for projections of at least this many rows
-
-
-def linear_q_gram_parts(M, N, K, heads, L, n_text_rows, n_std_groups):
-    """partial pairs per std group dsc_linear_q_gram_f16 writes for this shape, 0 = not covered (then: linear_ln + the statistics pass)"""
-    if not USE_XATTN_GRAM:
-        return 0
-    return int(_lib.load_library().dsc_linear_q_gram_parts(M, N, K, heads, L, n_text_rows, n_std_groups))
-
-
-def linear_q_gram(x, weight, bias, gram, heads, n_text_rows, n_std_groups, *, ln=None, scale=None):
-    """The cross-attention's query projection + the (sum a, sum a^2) partial pairs of the scores its output will produce against the
-    text keys (dsc_linear_q_gram_f16): x [Bq, L, K], weight [N, K] (from fold_layernorm when ln = (partials, cvec, eps) is given),
-    gram from xattn_gram_pack.  Returns (q [Bq, L, N], parts fp64 [n_std_groups, npart, 2] for region_xattn_packed(ext_stats=...))."""
-    _require_gpu(x, weight)
-    Bq, L, K = x.shape
-    N = weight.shape[0]
-    M = Bq * L
-    npart = linear_q_gram_parts(M, N, K, heads, L, n_text_rows, n_std_groups)
-    if not npart:
-        raise ValueError("linear_q_gram: shape not covered (linear_q_gram_parts() == 0)")
-    x2 = x.reshape(M, K)
-    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0 or not weight.is_contiguous():
-        raise ValueError("linear_q_gram: unit inner stride, 16-byte aligned rows and a contiguous weight are required")
-    G16, gscale, ksum = gram
-    if G16.shape[0] != n_text_rows or G16.shape[1] != heads or tuple(G16.shape[2:]) != gram_dims(N // heads) or ksum.shape != (n_text_rows, N):
-        raise ValueError("linear_q_gram: the Gram image does not match (text rows, heads, head dim)")
-    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    parts = torch.empty((n_std_groups, npart, 2), dtype=torch.float64, device=x.device)
-    part, cvec, eps, nb = None, None, 0.0, 0
-    if ln is not None:
-        part, cvec, eps = ln
-        nb = part.shape[1]
-        if part.shape[0] != M or part.dtype != torch.float32 or not part.is_contiguous() or cvec.numel() != N:
-            raise ValueError("linear_q_gram: statistics / cvec do not match the operands")
-    rc = _lib.load_library().dsc_linear_q_gram_f16(_p(x2), _p(weight), _p(bias), _p(out), M, N, K, x2.stride(0), N,
-                                                   _p(part), nb, _p(cvec), float(eps), _p(G16), _p(gscale), _p(ksum), heads, L,
-                                                   n_text_rows, n_std_groups, float(scale) if scale else 0.0, _p(parts), 0,
-                                                   _stream_ptr(x))
-    _lib.check(rc, "dsc_linear_q_gram_f16")
-    return out.reshape(Bq, L, N), parts
 
 
 USE_QKV_HEAD_MAJOR = os.environ.get("DSC_QKV_HEAD_MAJOR", "1") != "0"

@@ -41,10 +41,6 @@ extern "C" {
 #define DSC_FLAG_ROWS_PADDED     256u  /* dsc_region_xattn_fwd_packed only: `region_rows` is [n_rows][100] fp32 (row stride 100
                                           floats = the kernel's LDS table, zeros beyond column S, 16-byte aligned) instead
                                           of [n_rows][S]: the table goes to LDS as a flat 16-byte copy.  S <= 96 only. */
-#define DSC_FLAG_EXT_STATS       512u  /* dsc_region_xattn_fwd_packed only: `workspace` holds fp64 (sum a, sum a^2) partial pairs
-                                          [n_std_groups][npart][2] that ANOTHER kernel produced for this call's scores a = scale q.k^T
-                                          (npart = workspace_bytes / (16 n_std_groups); dsc_linear_q_gram_f16 writes them from the
-                                          to_q projection's epilogue): no statistics launch.  fp32 scores only. */
 #define DSC_FLAG_BIAS_IS_FINAL     2u  /* `region` already holds the additive bias (a custom weight_func was
                                           evaluated by the caller): add it as is, skip the statistics pass */
 
@@ -151,35 +147,6 @@ int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv, void* out,
                                 float sigma_host, const float* sigma_dev, float scale,
                                 int dtype, unsigned flags,
                                 void* workspace, size_t workspace_bytes, void* stream);
-
-/*
- * The cross-attention's query projection WITH the statistics of the scores its output will produce (round 4): q = x . w^T (+ bias),
- * optionally with the LayerNorm in front folded in exactly as dsc_linear_ln_f16 does (ln_in / ln_nb / ln_cvec / ln_eps) - the
- * `to_q` of reference attention_modify.py:458 - and, from the same launch, the fp64 (sum a, sum a^2) partial pairs of
- * a = scale * q.k^T over the text keys (attention_modify.py:90,96: the operand of `qk.std()`), which dsc_region_xattn_fwd_packed then
- * takes through DSC_FLAG_EXT_STATS instead of launching its own statistics pass.  Per head: sum_s a = scale q.(sum_s k_s) and
- * sum_s a^2 = scale^2 q^T (K^T K) q, so the epilogue needs of the keys only
- *   gram    fp16 [n_text_rows, heads, JP, KP]  K^T K / gscale per (text row, head), zero padded (JP = d rounded up to 32, KP to 16)
- *   gscale  fp32 [n_text_rows, heads]          the scale taken out of gram (max |K^T K| / 1024)
- *   ksum    fp32 [n_text_rows, N]              sum of the keys over s
- * (computed once per generation next to dsc_xattn_kv_pack).  x [M, K] with M = Bq * L rows, L rows per batch row; the text rows are
- * n_text_rows = Bq (row b meets text row b) or 2 Bq (shared CFG prefix: q was computed once per image and row b meets text rows b and
- * b + Bq; then n_std_groups must equal Bq).  Std group of q row b: b % n_std_groups (rows [u_0.., c_0..]).  `parts` receives
- * [n_std_groups][dsc_linear_q_gram_parts()][2] doubles; dsc_linear_q_gram_parts returns 0 for shapes this form does not cover
- * (N % 160, head dim not a divisor of 160, L % 64, ...): call dsc_linear_ln_f16 + the ordinary statistics pass then.
- * fp32-score semantics only (no DSC_FLAG_REF_FP16_ROUNDING emulation, no attention mask): relative difference of the resulting std
- * to the statistics kernel's ~5e-6 (the Gram matrix is held in fp16).
- */
-/* The three key-side operands above from k [n_text_rows, S, heads, d] (addressed through {sb, ss, sh} element strides as in
- * dsc_region_xattn_fwd; S <= 96, d <= 160, d % 8 == 0): gram holds dsc_xattn_gram_bytes() bytes, 16-byte aligned. */
-size_t dsc_xattn_gram_bytes(int n_text_rows, int heads, int d);
-int dsc_xattn_gram_pack(const void* k, void* gram, float* gscale, float* ksum, int n_text_rows, int heads, int S, int d,
-                        const int64_t k_strides[3], int dtype, void* stream);
-int dsc_linear_q_gram_parts(int64_t M, int N, int K, int heads, int L, int n_text_rows, int n_std_groups);
-int dsc_linear_q_gram_f16(const void* x, const void* w, const void* bias, void* out, int64_t M, int N, int K,
-                          int64_t ldx, int64_t ldo, const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps,
-                          const void* gram, const float* gscale, const float* ksum, int heads, int L,
-                          int n_text_rows, int n_std_groups, float scale, double* parts, int dtype, void* stream);
 
 /*
  * Flash self-attention forward - replaces `F.scaled_dot_product_attention(query, key, value)` on the self-attention

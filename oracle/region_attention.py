@@ -247,31 +247,3 @@ def ip_adapter_attn_processor(ip, attn, hidden_states, encoder_hidden_states=Non
         return torch.softmax((q @ k.transpose(-2, -1)) * attn.scale, dim=-1) @ v
 
     return _proc_common(attn, hidden_states, text, region_prompt, core_region, core_plain, ip_branch=branch)
-
-
-def score_moment_partials(q, k, n_std_groups, scale=None, rows_per_partial=64):
-    """(sum a, sum a^2) of the scores a = scale * q.k^T (attention_modify.py:90; the operand of `qk.std()`, :96) WITHOUT forming
-    them: per head  sum_s a = scale q.(sum_s k_s),  sum_s a^2 = scale^2 q^T (K^T K) q.  The checker of dsc_linear_q_gram_f16, whose
-    epilogue emits exactly these sums (with K^T K held in fp16: agreement ~1e-6 relative per partial).
-      q [Bq, L, H, d], k [Bt, S, H, d] (any float dtype; Bt = Bq, or 2 Bq when q was computed once per image for both CFG halves)
-    -> fp64 [n_std_groups, (Bt / n_std_groups) * L / rows_per_partial, 2]: one pair per (std group, text row of the group, block of
-    `rows_per_partial` query rows), groups as in the pipeline's row layout [u_0.., c_0..] (row b belongs to group b % n_std_groups)."""
-    Bq, L, H, d = q.shape
-    Bt = k.shape[0]
-    sc = float(scale) if scale else 1.0 / math.sqrt(d)
-    reps = Bt // Bq
-    qf, kf = q.double(), k.double().permute(0, 2, 1, 3)                      # k: [Bt, H, S, d]
-    G = kf.transpose(-1, -2) @ kf                                            # [Bt, H, d, d]
-    ksum = kf.sum(dim=2)                                                     # [Bt, H, d]
-    tiles = L // rows_per_partial
-    out = torch.zeros((n_std_groups, (Bt // n_std_groups) * tiles, 2), dtype=torch.float64, device=q.device)
-    for bq in range(Bq):
-        for r in range(reps):
-            bt = bq + r * Bq if reps > 1 else bq
-            g = bq % n_std_groups
-            rep_index = r if reps > 1 else bq // n_std_groups
-            s2 = torch.einsum("lhj,hjk,lhk->l", qf[bq], G[bt], qf[bq]) * sc * sc
-            s1 = torch.einsum("lhj,hj->l", qf[bq], ksum[bt]) * sc
-            out[g, rep_index * tiles:(rep_index + 1) * tiles, 0] = s1.view(tiles, rows_per_partial).sum(dim=1)
-            out[g, rep_index * tiles:(rep_index + 1) * tiles, 1] = s2.view(tiles, rows_per_partial).sum(dim=1)
-    return out
