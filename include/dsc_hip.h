@@ -321,7 +321,10 @@ int dsc_linear_ln_f16(const void* x, const void* w, const void* bias, const void
  *   v / 10 % 1000     tile height (64 or 128 token rows)                          e.g. 643 = 64-row tiles, 3 stages
  *   v / 10000 % 10    DMA-only loader waves: 4 = for every tile, 9 = never
  *   v / 100000 % 10   128-column tiles: 1 = never, 2 = wherever N is a multiple of 128
- *   v / 1000000       workgroup order: 1 = plain blockIdx, 2 = XCD-aware for every shape
+ *   v / 1000000 % 10  workgroup order: 1 = plain blockIdx, 2 = XCD-aware for every shape
+ *   v / 10000000 % 10 1 = non-temporal stores of the GEGLU output (measured: no effect)
+ *   v < 0             -v = the grid (workgroups) a plain GEMM must keep to take 128-column tiles (default 512: the throughput
+ *                     tier - 8 images per generation, coalesced requests; no batch-1 launch qualifies)
  * Every variant gives equal bytes (tests/test_unet_pipeline_gpu.py::test_linear_kernel_tilings_agree_bit_for_bit). */
 void dsc_debug_set_gemm_stages(int stages);
 int dsc_linear_qkv_f16(const void* x, const void* w, const void* bias, void* q_out, void* kv_out,
