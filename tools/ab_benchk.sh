@@ -7,7 +7,7 @@ cd $root
 for spec in "$@"; do
   set -- $spec; name=$1; shift
   ( for kv in "$@"; do export "$kv"; done
-    timeout -k 10 300 python3 bench.py --images-per-gpu $k --steps $(( 16 / k + 2 )) --warmup 1 --in-flight 1 --no-cpu-baseline --no-batched-roofline --no-coalesced > gpurun_out/$out/bk${k}_$name.json 2> gpurun_out/$out/bk${k}_$name.err ) || { echo "$name failed"; tail -3 gpurun_out/$out/bk${k}_$name.err; exit 1; }
+    timeout -k 10 300 python3 bench.py --images-per-gpu $k --steps $(( 16 / k + 2 )) --warmup 1 --in-flight ${F:-1} --no-cpu-baseline --no-batched-roofline --no-coalesced > gpurun_out/$out/bk${k}_$name.json 2> gpurun_out/$out/bk${k}_$name.err ) || { echo "$name failed"; tail -3 gpurun_out/$out/bk${k}_$name.err; exit 1; }
   python3 -c "
-import json; r=json.load(open('gpurun_out/$out/bk${k}_$name.json')); print('k=$k $name', r['value'], 'images/s', r['ms_per_step'], 'ms/gen')"
+import json; r=json.load(open('gpurun_out/$out/bk${k}_$name.json')); print('k=$k f=${F:-1} $name', r['value'], 'images/s', r['ms_per_step'], 'ms/gen')"
 done
