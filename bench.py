@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--images-per-gpu", type=int, default=1)
     ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--model", choices=["sd15", "sdxl-shape"], default="sd15",
+                    help="UNet geometry: sd15 (BASELINE configs[0..3], the headline) or the SDXL-base SHAPE of configs[4] (3 levels, transformer "
+                         "depth 0 / 2 / 10, 64-channel heads, context 2048; use with --size 1024 --images-per-gpu 2: 16 images over 8 GPUs).  "
+                         "The reference has no SDXL pipeline (SURVEY.md 8d): the same processor contract on an SDXL-shaped UNet, random weights")
     ap.add_argument("--denoise-steps", type=int, default=25)
     ap.add_argument("--regions", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true")
@@ -456,12 +460,12 @@ def main():
     ops.GRAPHS_ENABLED = not a.no_graph
     torch.backends.cudnn.deterministic = bool(a.deterministic_conv)
 
-    cfg = UNetConfig.sd15()
+    cfg = UNetConfig.sd15() if a.model == "sd15" else UNetConfig.sdxl_base()
     torch.manual_seed(0)
     with torch.device(dev):
         unet = UNet2DConditionModel(cfg)
     unet = unet.half().eval()
-    emb, ids, state, tok = synthetic_inputs(a.size, a.regions)
+    emb, ids, state, tok = synthetic_inputs(a.size, a.regions, ctx=cfg.cross_attention_dim)
     emb = emb.to(dev)
     if dist:                                                    # rank 0's embeddings are THE embeddings
         emb = broadcast_generation_inputs(emb, src=0)
@@ -556,11 +560,12 @@ def main():
     res = None
     if rank == 0:
         res = {
-            "metric": "512x512 images/sec, SD1.5 25-step DPM++2M Karras with region-biased cross-attention",
+            "metric": ("512x512 images/sec, SD1.5 25-step DPM++2M Karras with region-biased cross-attention" if a.model == "sd15" and a.size == 512
+                       else f"{a.size}x{a.size} images/sec, {a.model} UNet, 25-step DPM++2M Karras with region-biased cross-attention"),
             "value": round(images / dt_seq, 4), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt_seq / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"SD1.5 {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
+            "config": {"workload": f"{'SD1.5' if a.model == 'sd15' else 'SDXL-base-SHAPED UNet (configs[4] geometry)'} {a.size}x{a.size}, {a.denoise_steps}-step DPM++2M Karras, CFG 7.5, "
                                    f"{a.regions} region masks, {n_img} image(s) per generation, "
                                    f"1 generation(s) in flight per GPU",
                        "images_per_gpu": n_img, "parallelism": f"dp{world} (independent images, no per-step collective)",
@@ -578,7 +583,7 @@ def main():
             res["roofline_at_8_images"] = {"region_xattn": pick(roofline_region_xattn(dev, 8)),
                                            "self_attn": pick(roofline_self_attn(dev, 8)),
                                            "conv3x3": pick(roofline_conv3x3(dev, 8))}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.model == "sd15":
             from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
             rs = encode_region_map(pipe, state, a.size, a.size, 1, text_ids=ids)
             sig = pipe.get_sigmas(a.denoise_steps, {"scheduler": "karras"}).half()
@@ -701,7 +706,7 @@ def main():
                                   "per_rank_images_per_s": rates_fl, "max_over_ranks_s": round(dt, 4),
                                   "outputs_finite": finite and all(bool(torch.isfinite(o).all().item()) for o in slot_outs),
                                   "workload": res["config"]["workload"].replace("1 generation(s) in flight", f"{nfl} generation(s) in flight")})
-    if res is not None and world == 1 and n_img == 1 and not a.no_coalesced and not a.decode and not a.no_graph:
+    if res is not None and world == 1 and n_img == 1 and not a.no_coalesced and not a.decode and not a.no_graph and a.model == "sd15":
         # Serving mode (not the headline, which stays BASELINE configs[1]: batch-1 generations): k CONCURRENT batch-1 requests of
         # the same workload - own start latent each, configs[1]'s prompt and masks - denoised by ONE captured step per sigma
         # (txt2img_coalesced: per-request std groups and tables, every kernel on k times the rows), f such generations in flight
