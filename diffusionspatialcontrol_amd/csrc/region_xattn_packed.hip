@@ -362,15 +362,7 @@ __global__ __launch_bounds__(kThreads, (NK <= 5 ? 2 : 1)) void xp_fwd(XpParams p
                     const h8_t vf = *reinterpret_cast<const h8_t*>(img + ((P::KFR + dm * 6 + tt) * 64 + lane) * 8);
                     o = mfma_32x32x16(vf, pf[tt], o);
                 }
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const int dd0 = 32 * dm + 8 * g4 + 4 * hh;
-                    if (row_ok && dd0 < p.d) {
-                        const h4_t ov = {(half_t)(o[4 * g4] * oscale), (half_t)(o[4 * g4 + 1] * oscale),
-                                         (half_t)(o[4 * g4 + 2] * oscale), (half_t)(o[4 * g4 + 3] * oscale)};
-                        *reinterpret_cast<h4_t*>(ob + dd0) = ov;
-                    }
-                }
+                store_o_block(ob, o, oscale, dm, hh, p.d, row_ok, p.wide_store != 0);
             }
         }
         XP_STAMP(6)
@@ -724,6 +716,7 @@ extern "C" int dsc_region_xattn_fwd_packed(const void* q, const void* packed_kv,
     p.std_out = static_cast<float*>(g_debug_stamps);
     pp.img = static_cast<const half_t*>(packed_kv);
     pp.ids = region_ids; pp.rows = region_rows; pp.NU = has_bias ? n_rows : 0;
+    p.wide_store = (aligned16(out) && o_strides[0] % 8 == 0 && o_strides[1] % 8 == 0 && o_strides[2] % 8 == 0 && !(flags & 1024u)) ? 1 : 0;   // (flag 1024: A/B, 8-byte pieces)
     if (has_bias) {
         const size_t need = (size_t)n_std_groups * p.npart * 2 * sizeof(double);
         if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 7)) return DSC_ERR_WORKSPACE;

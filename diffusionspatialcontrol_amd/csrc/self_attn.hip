@@ -49,6 +49,7 @@ struct SaParams {
     long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
     unsigned k_bytes, v_bytes;   // extent of one (b, h) slice of K / V: ((S - 1) * row stride + d) * 2
     unsigned long long* stamps;  // diagnostics; the stamping wave's index rides in the pointer's low three bits (no extra SGPR)
+    int wide_store;              // out and its strides are 16-byte aligned: the epilogue writes 16-byte row pieces
 };
 
 // D8 = 0: generic image - K rows of 2 NK + 1 chunks (2 NK operand chunks, zero beyond the head dim, + 1 chunk that makes the
@@ -543,20 +544,9 @@ __global__ __launch_bounds__(64 * (WAVES + NLOAD), MINW) void self_attn_fwd(SaPa
     }
     const float inv = 1.f / l_tot;
     const int qrow = q0 + r_e;
-    if (qrow < p.L) {
-        half_t* op = p.out + b * p.osb + h * p.osh + (long long)qrow * p.osl;
+    half_t* op = p.out + b * p.osb + h * p.osh + (long long)qrow * p.osl;
 #pragma unroll
-        for (int dm = 0; dm < DM; ++dm)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int dd0 = 32 * dm + 8 * g4 + 4 * hh_e;
-                if (dd0 < p.d) {
-                    const h4_t ov = {(half_t)(o[dm][4 * g4] * inv), (half_t)(o[dm][4 * g4 + 1] * inv),
-                                     (half_t)(o[dm][4 * g4 + 2] * inv), (half_t)(o[dm][4 * g4 + 3] * inv)};
-                    *reinterpret_cast<h4_t*>(op + dd0) = ov;
-                }
-            }
-    }
+    for (int dm = 0; dm < DM; ++dm) store_o_block(op, o[dm], inv, dm, hh_e, p.d, qrow < p.L, p.wide_store != 0);
 }
 
 template <int NK, int WAVES, int MINW, int D8 = 0, int NLOAD = 0, int STAGGER = 0>
@@ -687,6 +677,7 @@ extern "C" int dsc_self_attn_fwd(const void* q, const void* k, const void* v, vo
     p.ksb = k_strides[0]; p.kss = k_strides[1]; p.ksh = k_strides[2];
     p.vsb = v_strides[0]; p.vss = v_strides[1]; p.vsh = v_strides[2];
     p.osb = o_strides[0]; p.osl = o_strides[1]; p.osh = o_strides[2];
+    p.wide_store = ((reinterpret_cast<uintptr_t>(out) & 15) == 0 && o_strides[0] % 8 == 0 && o_strides[1] % 8 == 0 && o_strides[2] % 8 == 0) ? 1 : 0;
     p.k_bytes = (unsigned)kext; p.v_bytes = (unsigned)vext;
     p.stamps = g_sa_stamps ? reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(g_sa_stamps) | (uintptr_t)(g_sa_stamp_wave & 7)) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -24,6 +24,7 @@ struct XattnParams {
     int nchunks, tiles_per_wave, npart, xcd_map;
     long long qsb, qsl, qsh, ksb, kss, ksh, vsb, vss, vsh, osb, osl, osh;
     unsigned flags;
+    int wide_store;              // out and its strides are 16-byte aligned: 16-byte row pieces (store_o_block, dsc_common.h)
     // additive attention mask of the statistics pass (dsc_region_xattn_std_masked; reference attention_modify.py:85-95:
     // the std is taken over scale * q.k^T + mask): fp32, element (bh, l, s) at mask[bh * msbh + l * msl + s]; strides 0 = broadcast
     const float* mask; long long msbh, msl;
