@@ -575,6 +575,46 @@ def test_coalesced_requests_equal_their_single_runs(sd15):
     assert e.max().item() < 2.5e-3 * ref.abs().max().item()
 
 
+def test_coalesced_requests_beyond_32_distinct_table_rows():
+    """Nine coalesced requests whose region tables together hold MORE than 32 distinct rows per level (the prepared-operand kernels'
+    limit): the step must take the dense-table route (static buffers refreshed in place) and every request must still equal its own
+    `txt2img` call.  Toy-width UNet at 128x128 (levels 256 / 64 / 16 / 4), four one-cell masks per request with request-specific
+    weights -> 4 distinct rows per request and level, 36 in the batch."""
+    cfg, pipe = _tiny_pipe(3)
+    tok = FakeTokenizer()
+    g = torch.Generator().manual_seed(21)
+    reqs = []
+    for i in range(9):
+        words = [f"object{r}a object{r}b" for r in range(4)]
+        ids = [49406, 320]
+        for w in words:
+            ids += tok(w).input_ids
+        ids = ids + [49407] * (77 - len(ids))
+        pos = np.array([ids], dtype=np.int64)
+        state = {}
+        for r, w in enumerate(words):
+            m = np.full((128, 128), 255, dtype=np.uint8)
+            m[(r // 2) * 64:(r // 2 + 1) * 64, (r % 2) * 64:(r % 2 + 1) * 64] = 0
+            state[w] = {"map": m, "weight": 0.3 + 0.05 * i + 0.01 * r, "mask_outsides": 0.0}
+        emb = torch.randn(2, 77, cfg.cross_attention_dim, generator=g).half()
+        reqs.append({"prompt_embeds": emb[1:2].cuda(), "negative_prompt_embeds": emb[0:1].cuda(), "text_input_ids": [pos.copy(), pos],
+                     "region_map_state": state, "latents": torch.randn(1, 4, 16, 16, generator=g).half().cuda()})
+    kw = dict(height=128, width=128, num_inference_steps=4, guidance_scale=7.5, output_type="latent", sampler_opt={"scheduler": "karras"})
+    from diffusionspatialcontrol_amd.modules.encode_region_map_function import encode_region_map
+    per = [encode_region_map(pipe, r["region_map_state"], 128, 128, 1, text_ids=r["text_input_ids"]) for r in reqs]
+    merged = pipe._coalesce_region_tables(per)
+    assert len(torch.unique(merged[256].reshape(-1, 77), dim=0)) > 32 and pipe._compress_tables(merged) is None      # the dense route
+    got = pipe.txt2img_coalesced(reqs, **kw)
+    scale = max(o.float().abs().max().item() for o in got)
+    for i, r in enumerate(reqs):
+        single = pipe.txt2img(None, latents=r["latents"], region_map_state=r["region_map_state"], sampler_name="sample_dpmpp_2m",
+                              prompt_embeds=r["prompt_embeds"], negative_prompt_embeds=r["negative_prompt_embeds"],
+                              text_input_ids=r["text_input_ids"], **kw)[0]
+        d = (got[i].float() - single.float()).abs().max().item()
+        assert torch.isfinite(got[i]).all() and d < 4e-3 * scale, (i, d, scale)
+    assert (got[0].float() - got[1].float()).abs().max().item() > 1e-2 * scale
+
+
 def test_coalesced_pair_25_steps_image0_vs_oracle(sd15):
     """configs[1]'s request coalesced with a second, different request (k = 2): all 25 DPM++ 2M Karras steps; image 0 against the
     fp32 oracle's 25-step latents of the ONE-image run - the stated end-to-end tolerance (8e-3 max / 1e-3 mean of range) holds for
