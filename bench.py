@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--cpu-sample-steps", type=int, default=25,
                     help="denoising steps of the cpu_baseline leg (oracle on the host cores): all 25 by default (BASELINE.md section 2: "
                          "configs[1] timed in full, about two minutes on 16 cores); fewer -> extrapolated and labelled as such")
+    ap.add_argument("--cpu-budget-s", type=float, default=300.0,
+                    help="when the configs[0] single step predicts more than this for the cpu_baseline sample (few host cores), the "
+                         "sample is cut to the steps that fit (>= 3) and labelled as extrapolated; 0 = no limit")
     return ap.parse_args()
 
 
@@ -356,10 +359,12 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sample_steps, total_steps, config1=None):
+def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sample_steps, total_steps, config1=None, budget_s=0.0):
     """oracle on the host cores: configs[1] = the `total_steps` denoising steps of the same image, timed
     in full by default (`--cpu-sample-steps` < total: that many steps, extrapolated and labelled); `config1` = (region tables of
-    ONE mask) -> configs[0], one denoise step of a 64x64 latent with one region mask, timed in full"""
+    ONE mask) -> configs[0], one denoise step of a 64x64 latent with one region mask, timed in full.  `budget_s` > 0: when the
+    configs[0] step predicts more than that for the sample (a box that grants few host cores), the sample is cut to the steps
+    that fit (at least 3) and labelled as extrapolated - the default run has to finish within minutes on any box"""
     from oracle import unet_ref
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -371,12 +376,14 @@ def cpu_baseline(unet, cfg, sigmas, text, region_state, latents, guidance, sampl
         t0 = time.perf_counter()
         c1_ref = unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), config1, guidance, steps_limit=1)
         c1 = (time.perf_counter() - t0, c1_ref)
+        if budget_s > 0 and c1[0] * sample_steps > budget_s:
+            sample_steps = max(3, min(sample_steps, int(budget_s / c1[0])))
     t0 = time.perf_counter()
     ref = unet_ref.denoise_loop(sd, cfg, lat, sig, text.float().cpu(), region_state, guidance, steps_limit=sample_steps)
     dt = time.perf_counter() - t0
     per_image = dt / sample_steps * total_steps
     full = sample_steps >= total_steps
-    res = {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
+    res = {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port", "steps_timed": sample_steps,
            "sample": (f"all {total_steps} denoising steps of one 512x512 image (BASELINE configs[1]) through the fp32 torch oracle, "
                       f"timed in full: {dt:.1f} s" if full else
                       f"{sample_steps} of {total_steps} denoising steps of one 512x512 image through the fp32 torch oracle "
@@ -593,7 +600,8 @@ def main():
             first = next(iter(state))
             rs1 = encode_region_map(pipe, {first: state[first]}, a.size, a.size, 1, text_ids=ids)
             res["cpu_baseline"], ref, ref1 = cpu_baseline(unet, cfg, sig, text, rs, lat[:1], 7.5, a.cpu_sample_steps, a.denoise_steps,
-                                                          config1=rs1)
+                                                          config1=rs1, budget_s=a.cpu_budget_s)
+            a.cpu_sample_steps = res["cpu_baseline"]["steps_timed"]
             # the checker's other use: the timed GPU path and the CPU baseline computed the same thing on this sample
             got = gpu_sample(pipe, sig.to(dev), text.to(dev), rs, lat[:1], 7.5, a.cpu_sample_steps).float().cpu()
             err = (got - ref).abs()
