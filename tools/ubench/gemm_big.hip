@@ -24,6 +24,7 @@ struct P {
     int M, N, K;                // GEGLU: N = 2 x output columns
     int rm, cn;                 // row panels, column blocks
     int tiles;
+    long long* prof;            // [workgroup][wave][4] cycle sums (NULL: off)
 };
 
 __device__ __forceinline__ h8_t lds_frag(const half_t* tile, int row, int kchunk) {
@@ -96,14 +97,21 @@ __global__ __launch_bounds__(128 * WM + 64 * NLOAD, 1) void gemm_big(P p) {
         };
         for (int q = 0; q < STAGES - 1; ++q)
             if (q < Q) issue(q);
+        long long tw = 0, tb = 0, ti = 0;
         for (int q = 0; q < Q; ++q) {
+            const long long c0 = __builtin_amdgcn_s_memtime();
             const int younger = min(STAGES - 2, Q - 1 - q);
             if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kPieces) : "memory");
             else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kPieces) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long c1 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
+            const long long c2 = __builtin_amdgcn_s_memtime();
             if (q + STAGES - 1 < Q) issue((q + STAGES - 1) % STAGES);
+            const long long c3 = __builtin_amdgcn_s_memtime();
+            tw += c1 - c0; tb += c2 - c1; ti += c3 - c2;
         }
+        if (p.prof && lane == 0) { long long* d = p.prof + ((long long)wg * 16 + wave) * 4; d[0] = tw; d[1] = tb; d[2] = ti; d[3] = Q; }
         return;
     }
     // ---- computing waves: wave grid WM x 2, wave tile 64 x 64
@@ -117,10 +125,14 @@ __global__ __launch_bounds__(128 * WM + 64 * NLOAD, 1) void gemm_big(P p) {
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     int j = 0, kt = 0, rp = 0, cb = 0;
     tile_of(p, wg, 0, nwg, rp, cb);
+    long long tb = 0, tc = 0, te = 0;
     for (int q = 0; q < Q; ++q) {
+        const long long c0 = __builtin_amdgcn_s_memtime();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        const long long c1 = __builtin_amdgcn_s_memtime();
+        tb += c1 - c0;
         const half_t* a = lds + (q % STAGES) * kStage;
         const half_t* b = a + kA;
 #pragma unroll
@@ -135,6 +147,9 @@ __global__ __launch_bounds__(128 * WM + 64 * NLOAD, 1) void gemm_big(P p) {
                 for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma(wf[nt], xf, acc[mt][nt]);
             }
         }
+        asm volatile("s_nop 0" ::: "memory");
+        const long long c2 = __builtin_amdgcn_s_memtime();
+        tc += c2 - c1;
         if (++kt == nk) {
             // epilogue from registers: lane (r, hh) holds row m = ... + r, columns (i & 3) + 8 (i >> 2) + 4 hh of each fragment
             const int m0 = rp * BM + wm * 64;
@@ -193,8 +208,10 @@ __global__ __launch_bounds__(128 * WM + 64 * NLOAD, 1) void gemm_big(P p) {
                     for (int i = 0; i < 16; ++i) acc[a2][b2][i] = 0.f;
             kt = 0; ++j;
             tile_of(p, wg, j, nwg, rp, cb);
+            te += __builtin_amdgcn_s_memtime() - c2;
         }
     }
+    if (p.prof && lane == 0) { long long* d = p.prof + ((long long)wg * 16 + wave) * 4; d[0] = tb; d[1] = tc; d[2] = te; d[3] = Q; }
 }
 
 static float frand() { return (float)rand() / RAND_MAX * 2.f - 1.f; }
@@ -216,7 +233,7 @@ void run(const char* name, int M, int N, int K, int wgs_per_cu) {
     (void)hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemcpy(b, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
     (void)hipMemset(o, 0, (size_t)M * Nout * 2);
-    P p{x, w, b, o, M, N, K, (M + BM - 1) / BM, GEGLU ? N / 2 / 64 : N / 128, 0};
+    P p{x, w, b, o, M, N, K, (M + BM - 1) / BM, GEGLU ? N / 2 / 64 : N / 128, 0, nullptr};
     p.tiles = p.rm * p.cn;
     const int lds = STAGES * (BM + 128) * BK * 2;
     const int grid = 256 * wgs_per_cu;
@@ -249,14 +266,32 @@ void run(const char* name, int M, int N, int K, int wgs_per_cu) {
     }
     printf("%-34s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TFLOP/s  (%d tiles, %d wg/CU, lds %d KB)  max err %.4f%s\n", name, M, N, K, us, tf, p.tiles,
            wgs_per_cu, lds / 1024, worst, bad ? "  MISMATCH" : "");
+    {
+        long long* prof; const int grid2 = grid;
+        (void)hipMalloc(&prof, (size_t)grid2 * 16 * 4 * 8); (void)hipMemset(prof, 0, (size_t)grid2 * 16 * 4 * 8);
+        P p2 = p; p2.prof = prof;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM + 64 * NLOAD), lds, 0, p2);
+        (void)hipDeviceSynchronize();
+        std::vector<long long> h((size_t)grid2 * 16 * 4);
+        (void)hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
+        double c[3] = {0, 0, 0}, l[3] = {0, 0, 0}; double qc = 0, ql = 0;
+        for (int g = 0; g < grid2; ++g)
+            for (int wv = 0; wv < 2 * WM + NLOAD; ++wv) {
+                const long long* d = &h[((size_t)g * 16 + wv) * 4];
+                if (wv < 2 * WM) { for (int i = 0; i < 3; ++i) c[i] += d[i]; qc += d[3]; }
+                else { for (int i = 0; i < 3; ++i) l[i] += d[i]; ql += d[3]; }
+            }
+        printf("      per K tile (memtime ticks): computing waves barrier %.0f  loop %.0f  epilogue %.0f | loaders wait %.0f  barrier %.0f  issue %.0f\n",
+               c[0] / qc, c[1] / qc, c[2] / qc, l[0] / ql, l[1] / ql, l[2] / ql);
+        (void)hipFree(prof);
+    }
     (void)hipFree(x); (void)hipFree(w); (void)hipFree(b); (void)hipFree(o);
 }
 
 int main() {
     struct S { int M, N, K; bool geglu; };
-    const S shapes[] = {{65536, 2560, 320, true}, {16384, 5120, 640, true}, {4096, 10240, 1280, true},
-                        {65536, 640, 320, false}, {16384, 640, 640, false}, {4096, 1280, 1280, false},
-                        {65536, 1280, 1280, false}, {16384, 640, 2560, false}, {65536, 3840, 320, false}};
+    const S shapes[] = {{65536, 2560, 320, true}, {16384, 5120, 640, true},
+                        {65536, 640, 320, false}, {65536, 1280, 1280, false}, {16384, 640, 2560, false}};
     for (const S& s : shapes) {
         if (s.geglu) {
             run<4, 3, 8, true>("256x128 3 stages 8+8 waves", s.M, s.N, s.K, 1);
