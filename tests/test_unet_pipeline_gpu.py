@@ -626,6 +626,35 @@ def test_linear_layernorm_folding(ops, M, C, N, geglu):
         lib.dsc_debug_set_gemm_stages(0)
 
 
+@pytest.mark.parametrize("offset,outlier", [(8.0, 1.0), (30.0, 1.0), (2.0, 60.0)])
+def test_linear_layernorm_folding_with_large_means_and_outlier_channels(ops, offset, outlier):
+    """The folded LayerNorm subtracts mu * (row sums of W') from an accumulator that holds the UN-normalised row: rows whose mean
+    is many standard deviations (a DC offset of the residual stream) or that carry a few outlier channels (trained SD1.5 streams
+    do; the random-init parity cases do not) must not cost more accuracy than the unfused LayerNorm -> linear path loses to the
+    fp16 rounding of the normalised row.  Both against the fp32 function."""
+    M, C, N = 2048, 640, 640
+    g = torch.Generator().manual_seed(int(offset * 10 + outlier))
+    a = torch.randn(M, C, generator=g).half().cuda()
+    wo = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    x = torch.randn(M, C, generator=g) + offset
+    x[:, ::97] *= outlier                                                          # 7 channels, all rows
+    x = x.half().cuda()
+    gamma = (torch.randn(C, generator=g) * 0.3 + 1).half().cuda()
+    beta = (torch.randn(C, generator=g) * 0.2).half().cuda()
+    w = (torch.randn(N, C, generator=g) / math.sqrt(C)).half().cuda()
+    b = (torch.randn(N, generator=g) * 0.2).half().cuda()
+    s, st = ops.linear_ln(a, wo, None, residual=x, ln_stats=True)
+    w2, b2, cvec = ops.fold_layernorm(w, b, gamma, beta)
+    y = ops.linear_ln(s, w2, b2, ln=(st, cvec, 1e-5))
+    ref = F.layer_norm(s.float(), (C,), gamma.float(), beta.float(), 1e-5) @ w.float().t() + b.float()
+    _, hk = ops.add_layernorm(s, None, gamma, beta)
+    y0 = ops.linear(hk, w, b)
+    e_fold, e_plain = (y.float() - ref).abs(), (y0.float() - ref).abs()
+    assert torch.isfinite(y).all()
+    assert e_fold.mean().item() <= 2.0 * e_plain.mean().item() + 1e-3, (e_fold.mean().item(), e_plain.mean().item())
+    assert e_fold.max().item() <= 2.0 * e_plain.max().item() + 2e-2, (e_fold.max().item(), e_plain.max().item())
+
+
 @pytest.mark.parametrize("B,L,C,H,fold", [(2, 4096, 320, 8, True), (2, 1024, 640, 8, False), (3, 576, 320, 8, True), (16, 64, 320, 5, False),
                                          (1, 9216, 320, 8, False), (2, 1024, 640, 8, True), (2, 256, 1280, 8, True)])
 def test_linear_qkv_head_major(ops, B, L, C, H, fold):
@@ -1812,6 +1841,31 @@ def test_groupnorm_statistics_from_the_convolution_epilogue(ops, B, hw, cin, cou
         assert torch.equal(again, out) and torch.equal(ops.gn_partials_of(again).buf[..., 0, :], part.buf[..., 0, :])
         assert torch.equal(ops.groupnorm_apply_nhwc(again, ops.gn_partials_of(again), groups, gamma, beta, 1e-5, True),
                            ops.groupnorm_apply_nhwc(out, part, groups, gamma, beta, 1e-5, True))
+
+
+@pytest.mark.parametrize("offset", [12.0, 60.0])
+def test_groupnorm_epilogue_statistics_with_a_large_channel_offset(ops, offset):
+    """The epilogue statistics are fp32 (sum, sum of squares) partials per (pixel tile, group) reduced in fp64: a group whose mean is
+    tens of standard deviations (a large bias / DC offset of the residual stream, as trained checkpoints have in some channels)
+    must normalise as well from them as from the two-launch GroupNorm's own pass over the tensor.  Against fp32 group_norm."""
+    B, hw, cin, cout, groups = 2, 32, 320, 640, 32
+    g = torch.Generator().manual_seed(int(offset))
+    x = (torch.randn(B, cin, hw, hw, generator=g) * 0.7).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).half().cuda().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(cout, generator=g) * 0.2
+    bias[: cout // 2] += offset                                  # half of the groups sit far from zero
+    bias = bias.half().cuda()
+    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).half().cuda()
+    beta = (0.1 * torch.randn(cout, generator=g)).half().cuda()
+    out = ops.conv3x3_gn(x, w, groups, bias=bias)
+    part = ops.gn_partials_of(out)
+    assert part is not None
+    gref = F.group_norm(out.float(), groups, gamma.float(), beta.float(), 1e-5)
+    one = ops.groupnorm_apply_nhwc(out, part, groups, gamma, beta, 1e-5, False)
+    two = ops.groupnorm_silu_nhwc(out, groups, gamma, beta, 1e-5, False)
+    e1, e2 = (one.float() - gref).abs(), (two.float() - gref).abs()
+    assert e1.max().item() <= 2.0 * e2.max().item() + 4e-3 and e1.mean().item() <= 2.0 * e2.mean().item() + 2e-4, \
+        (e1.max().item(), e2.max().item(), e1.mean().item(), e2.mean().item())
 
 
 @pytest.mark.parametrize("B,L,K,N,groups", [(2, 4096, 320, 320, 32), (2, 1024, 640, 640, 32), (2, 4096, 960, 320, 32), (2, 1024, 1920, 640, 32),
