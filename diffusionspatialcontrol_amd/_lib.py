@@ -101,9 +101,6 @@ _SIGNATURES = {
     "dsc_linear_gn_f16": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                           [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "dsc_groupnorm_apply_nhwc": (ctypes.c_int, [_vp] * 5 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _vp]),
-    "dsc_linear_gnfold_tile_rows": (ctypes.c_int, [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
-    "dsc_linear_gnfold_f16": (ctypes.c_int, [_vp] * 4 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, _vp,
-                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_float, _vp, ctypes.c_int, _vp]),
     "dsc_softmax_rows_f16": (ctypes.c_int, [_vp, _vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_float,
                                             ctypes.c_int, _vp]),
 }

@@ -71,13 +71,6 @@ struct GemmParams {
     // that has a row per CFG branch): row m adds residual row m % res_rows; res_rows % BM == 0, so a row tile lies in one copy
     int res_rows; FastDiv fd_res;
     long long* stamps;           // diagnostics (dsc_debug_set_gemm_stamps): 8 x int64 per workgroup, NULL in normal calls
-    // folded GroupNorm of the INPUT (dsc_linear_gnfold_f16): x = the un-normalised token-major tensor [B][gf_L][K] whose producer
-    // emitted the partial sums gf_part[b][pt][g][which][2] (gn_partials.h; 32 groups of gf_cpg channels), w = W diag(gamma), bias =
-    // b + W beta.  Every x fragment is centred and scaled on its way into the MFMA: fp16((x - m16[k]) * r16[k]) with m16 = the fp16
-    // rounding of its group's mean and r16 of its 1/std - the subtraction of two fp16 values that close is exact or rounds relative
-    // to the DIFFERENCE, so nothing is amplified by mean / std - and the epilogue subtracts what the rounding of the mean left:
-    // colb[n] = sum_g (mu_g - m16_g) r16_g gf_wg[n][g], gf_wg[n][g] = sum of w[n][k] over the group's channels.
-    const float* gf_part; const float* gf_wg; int gf_PT, gf_cpg, gf_L, gf_lds; float gf_eps; FastDiv fd_gf_cpg;
     int nt_store;                // GEGLU: the hidden tensor (written once, read once by the next GEMM) with non-temporal stores
 };
 
@@ -124,13 +117,10 @@ __device__ __forceinline__ void row_stats(const GemmParams& p, long long m, floa
 //
 // NT = 2: the workgroup's tile is 128 output columns wide (wave tile 64 x 64: one LDS fragment read per MFMA instead of 1.5,
 // and a third less L2 -> LDS traffic per output than two 128 x 64 tiles - the many-workgroup GEMMs are bound by exactly that).
-//
-// GNF: the GroupNorm in front of this GEMM folded into it (GemmParams::gf_*): 64-column tiles, no LayerNorm fold, no GEGLU.
-template <bool GEGLU, int STAGES, int BM, int NLOAD, int NT = 1, bool GNF = false>
+template <bool GEGLU, int STAGES, int BM, int NLOAD, int NT = 1>
 __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))) void gemm_tn_f16(GemmParams p) {
     static_assert(BM == 128 || (BM == 64 && !GEGLU), "tile heights");
     static_assert(NT == 1 || (NT == 2 && BM == 128 && NLOAD == 0), "tile widths");
-    static_assert(!GNF || (NT == 1 && !GEGLU), "folded GroupNorm: plain 64-column tiles");
     constexpr bool LOADER = NLOAD > 0;
     constexpr int NISS = LOADER ? NLOAD : 4;                 // waves that issue DMA
     constexpr int MT = BM / 64;                              // 32-row fragments per wave
@@ -215,7 +205,6 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
 #pragma unroll
             for (int st = 0; st < STAGES - 1; ++st)
                 if (st < nk) issue(st, st);
-            if constexpr (GNF) { __syncthreads(); __syncthreads(); }   // the two barriers of the computing waves' statistics prologue
             for (int kt = 0; kt < nk; ++kt) {
                 wait_tile(kt);
                 __builtin_amdgcn_s_barrier();                // publishes tile kt; every computing wave has left tile kt-1's stage
@@ -254,51 +243,6 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             cpre[3] = *reinterpret_cast<const f4x_t*>(p.ln_c + Nh + n0 + ech * 8 + 4);
         }
     }
-    // folded GroupNorm: (mean, 1/std) of the tile's image from the producer's partial sums, as gn_nhwc_apply takes them (fp64,
-    // fixed order), then the per-channel fp16 centre / scale vectors of the K loop and the epilogue's column constants
-    half_t* gf_m16 = reinterpret_cast<half_t*>(smem + p.gf_lds);  // [K]
-    half_t* gf_r16 = gf_m16 + p.K;                                 // [K]
-    float* gf_colb = reinterpret_cast<float*>(gf_r16 + p.K);      // [64]
-    if constexpr (GNF) {
-        float* gf_gr = gf_colb + 64;                               // [32][2]: (mu - m16) r16, and (m16, r16) as floats behind it
-        double* red = reinterpret_cast<double*>(smem + (size_t)(STAGES - 1) * kStage * sizeof(half_t));   // the ring's last stage: free until the loop's first barrier
-        const int t = threadIdx.x, g = t & 31, part = t >> 5;     // computing waves only: t < 256
-        const int b_img = m0 / p.gf_L;
-        const float* fsrc = p.gf_part + ((long long)b_img * p.gf_PT * 32 + g) * 4;
-        const bool straddles = (g * p.gf_cpg) / 64 != ((g + 1) * p.gf_cpg - 1) / 64;
-        double a1 = 0.0, a2 = 0.0;
-        for (int i = part; i < p.gf_PT; i += 8) {
-            const f4x_t v = *reinterpret_cast<const f4x_t*>(fsrc + (long long)i * 32 * 4);
-            a1 += (double)v[0]; a2 += (double)v[1];
-            if (straddles) { a1 += (double)v[2]; a2 += (double)v[3]; }
-        }
-        red[(part * 32 + g) * 2] = a1; red[(part * 32 + g) * 2 + 1] = a2;
-        __syncthreads();
-        if (t < 32) {
-            double t1 = 0.0, t2 = 0.0;
-            for (int q = 0; q < 8; ++q) { t1 += red[(q * 32 + t) * 2]; t2 += red[(q * 32 + t) * 2 + 1]; }
-            const double n = (double)p.gf_L * p.gf_cpg;
-            const double m = t1 / n;
-            double var = t2 / n - m * m;
-            var = var > 0.0 ? var : 0.0;
-            const half_t m16 = (half_t)(float)m, r16 = (half_t)(float)(1.0 / sqrt(var + (double)p.gf_eps));
-            gf_gr[2 * t] = (float)((m - (double)(float)m16) * (double)(float)r16);
-            gf_gr[64 + 2 * t] = (float)m16; gf_gr[64 + 2 * t + 1] = (float)r16;
-        }
-        __syncthreads();
-        for (int k = t; k < p.K; k += T) {
-            const int gk = fdiv(k, p.fd_gf_cpg);
-            gf_m16[k] = (half_t)gf_gr[64 + 2 * gk]; gf_r16[k] = (half_t)gf_gr[64 + 2 * gk + 1];
-        }
-        if (t < 64) {
-            const float* wg = p.gf_wg + (long long)(n0 + t) * 32;
-            float sacc = 0.f;
-#pragma unroll 8
-            for (int q = 0; q < 32; ++q) sacc += gf_gr[2 * q] * wg[q];
-            gf_colb[t] = sacc;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the vectors are in LDS before the loop's first (raw) barrier
-    }
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt % STAGES;
         if (!LOADER) wait_tile(kt);
@@ -316,11 +260,7 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
             for (int nt = 0; nt < NT; ++nt) wf[nt] = lds_frag(b, wn * (32 * NT) + nt * 32 + r, 2 * ks + hh);   // W[n][16 ks + 8 hh ..]
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                h8_t xf = lds_frag(a, wm * (BM / 2) + mt * 32 + r, 2 * ks + hh);   // X[m][...]
-                if constexpr (GNF) {
-                    const int kc = (kbeg + kt) * BK + (2 * ks + hh) * 8;
-                    xf = (xf - *reinterpret_cast<const h8_t*>(gf_m16 + kc)) * *reinterpret_cast<const h8_t*>(gf_r16 + kc);
-                }
+                const h8_t xf = lds_frag(a, wm * (BM / 2) + mt * 32 + r, 2 * ks + hh);   // X[m][...]
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma_32x32x16(wf[nt], xf, acc[mt][nt]);
             }
@@ -433,7 +373,6 @@ __global__ __launch_bounds__(T + 64 * NLOAD, (NLOAD ? 4 : (STAGES <= 3 ? 2 : 1))
                 for (int j = 0; j < 8; ++j) {
                     float a = sp[j];
                     if (p.ln_in) a = rs * (a - mu * cv_[j]);
-                    if constexpr (GNF) a -= gf_colb[ch * 8 + j];
                     o[j] = (half_t)(a + (float)bv[j] + (float)rv[j]);
                     const float f = (float)o[j];                 // statistics of the fp16 row, as the LayerNorm kernel takes them
                     s1 += f; s2 += f * f;
@@ -540,12 +479,11 @@ extern "C" int dsc_linear_f16(const void* x, const void* w, const void* bias, co
 
 namespace {
 struct GnArgs { float* part; int groups; int rows_per_image; };
-struct GfArgs { const float* part; const float* wg; int part_rows, groups, rows_per_image; float eps; };   // GroupNorm of the input, folded
 int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
                 int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits = 1, float* ws = nullptr,
-                const GnArgs* gn = nullptr, const GfArgs* gf = nullptr);
+                const GnArgs* gn = nullptr);
 int gemm_tile_rows(int64_t M, int N, bool geglu);
 }
 
@@ -571,7 +509,7 @@ namespace {
 int linear_impl(const void* x, const void* w, const void* bias, const void* residual, void* out,
                 int64_t M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldo, int geglu,
                 const float* ln_in, int ln_nb, const float* ln_cvec, float ln_eps, float* ln_out,
-                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits, float* ws, const GnArgs* gn, const GfArgs* gf) {
+                int dtype, void* stream, void* kv_out, int heads, int seq_len, int splits, float* ws, const GnArgs* gn) {
     if ((ln_in && (!ln_cvec || ln_nb <= 0)) || (ln_out && geglu)) return DSC_ERR_BAD_ARG;
     if (ln_in && !al16(ln_cvec)) return DSC_ERR_UNSUPPORTED;       // read as float4 pairs
     if (!x || !w || !out || M <= 0 || N <= 0 || K <= 0) return DSC_ERR_BAD_ARG;
@@ -605,10 +543,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
                              reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 0>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64, 0>),
                              reinterpret_cast<const void*>(&gemm_tn_f16<true, 3, 128, 4>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128, 4>),
                              reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128, 0, 2>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0, 2>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 4, 1, true>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 64, 0, 1, true>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 64, 0, 1, true>),
-                             reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0, 1, true>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 3, 128, 0, 1, true>)};
+                             reinterpret_cast<const void*>(&gemm_tn_f16<true, 2, 128, 0, 2>), reinterpret_cast<const void*>(&gemm_tn_f16<false, 2, 128, 0, 2>)};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -621,13 +556,6 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
             M % gn->rows_per_image != 0)
             return DSC_ERR_UNSUPPORTED;
         p.gn_part = gn->part; p.gn_G = gn->groups; p.gn_cpg = N / gn->groups; p.gn_L = gn->rows_per_image;
-    }
-    if (gf) {
-        if (geglu || kv_out || splits > 1 || ln_in || gn || residual || gf->groups != 32 || K % 32 != 0 || K / 32 > 64 || K / 32 < 2 ||
-            K > 2560 || gf->rows_per_image % bm != 0 || M % gf->rows_per_image != 0 || gf->part_rows <= 0 || !gf->part || !gf->wg)
-            return DSC_ERR_UNSUPPORTED;
-        p.gf_part = gf->part; p.gf_wg = gf->wg; p.gf_PT = gf->part_rows; p.gf_cpg = K / 32; p.gf_L = gf->rows_per_image;
-        p.gf_eps = gf->eps; p.fd_gf_cpg = make_fastdiv(K / 32, K);
     }
     // (measured, tools/mb_gemm.py: M=512 N=1280 K=1280 11.8 -> 8.1 us, M=8192 N=320 K=320 9.1 -> 7.5, M=8192 N=320 K=1280 24.4 ->
     // 20.7; at 480+ workgroups of 128 rows the taller tile wins: M=2048 N=1920 K=640 12.3 vs 13.5)
@@ -674,7 +602,7 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     // workgroups (dsc_debug_set_gemm_stages(-n) sets it).  Not with GroupNorm partial sums (gn_tile_partials is written for
     // 64-column tiles).
     const long long wide_wgs = (long long)mb * (N / 128);
-    const bool wide = wide_ok && p.splits == 1 && !gn && !gf &&
+    const bool wide = wide_ok && p.splits == 1 && !gn &&
                       (g_gemm_nt == 2 || (g_gemm_nt == 0 && (geglu ? wide_wgs >= 256 : wide_wgs >= g_gemm_wide_min)));
     if (wide) {
         nb = N / 128;
@@ -693,27 +621,11 @@ int linear_impl(const void* x, const void* w, const void* bias, const void* resi
     const size_t epi = (size_t)bm * kEpiStride * sizeof(float) + (size_t)bm * 2 * sizeof(float) +
                        (gn ? (size_t)dsc_gn::kScratchFloats * sizeof(float) : 0);
     if (lds < epi) lds = epi;
-    const bool loaders = g_gemm_loaders == 4 || (g_gemm_loaders == 0 && bm == 64 && stages == 3 && g_dsc_tuning_profile == DSC_TUNE_LATENCY);
-    if (gf) {                                                    // the folded GroupNorm's vectors live behind the ring / epilogue stage
-        if (loaders && bm == 64) {
-            lds = (size_t)3 * stage_halves(bm) * sizeof(half_t);
-            if (lds < epi) lds = epi;
-        }
-        lds = (lds + 15) & ~(size_t)15;
-        p.gf_lds = (int)lds;
-        lds += (size_t)K * 4 + 64 * sizeof(float) + 128 * sizeof(float);
-        if (loaders && bm == 64) DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 4, 1, true>), grid, dim3(T + 256), lds, st, p);
-        else if (bm == 64 && stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 64, 0, 1, true>), grid, block, lds, st, p);
-        else if (bm == 64) DSC_LAUNCH((gemm_tn_f16<false, 3, 64, 0, 1, true>), grid, block, lds, st, p);
-        else if (stages == 2) DSC_LAUNCH((gemm_tn_f16<false, 2, 128, 0, 1, true>), grid, block, lds, st, p);
-        else DSC_LAUNCH((gemm_tn_f16<false, 3, 128, 0, 1, true>), grid, block, lds, st, p);
-        return hipGetLastError() == hipSuccess ? DSC_OK : DSC_ERR_LAUNCH;
-    }
     // Four DMA-only loader waves beside the four computing ones: in the step 1-3 % on the 64-row-tile GEMMs (10.7 -> 10.6,
     // 9.6 -> 9.3, 8.9 -> 8.7 us; 5-20 % back to back with warm weights, tools/chk_gemm_loader.py), while the 128-row tiles
     // of the big grids keep the two-stage ring and three workgroups per CU (with loaders and three stages: GEGLU 29.7 -> 31.9 us)
     // - under DSC_TUNE_LATENCY only: eight-wave workgroups cost the other stream's kernels their wave slots
-    if (loaders) {
+    if (g_gemm_loaders == 4 || (g_gemm_loaders == 0 && bm == 64 && stages == 3 && g_dsc_tuning_profile == DSC_TUNE_LATENCY)) {
         lds = (size_t)3 * stage_halves(bm) * sizeof(half_t);
         if (lds < epi) lds = epi;
         const dim3 block8(T + 256);
@@ -762,25 +674,6 @@ extern "C" int dsc_linear_gn_f16(const void* x, const void* w, const void* bias,
     const GnArgs gn{gn_part, groups, rows_per_image};
     return linear_impl(x, w, bias, residual, out, M, N, K, ldx, ldr, ldo, 0, nullptr, 0, nullptr, 0.f, nullptr, dtype, stream,
                        nullptr, 0, 0, 1, nullptr, &gn);
-}
-
-// rows of a row tile under dsc_linear_gnfold_f16 (the caller checks rows_per_image against it), 0 when the shape is not covered
-extern "C" int dsc_linear_gnfold_tile_rows(int64_t M, int N, int K, int rows_per_image, int groups) {
-    if (M <= 0 || N <= 0 || K <= 0 || rows_per_image <= 0 || groups != 32 || K % BK != 0 || N % BN != 0 || K / 32 > 64 || K > 2560 ||
-        M % rows_per_image != 0)
-        return 0;
-    const int bm = gemm_tile_rows(M, N, false);
-    return rows_per_image % bm == 0 ? bm : 0;
-}
-
-extern "C" int dsc_linear_gnfold_f16(const void* x, const void* w, const void* bias, void* out, int64_t M, int N, int K,
-                                     int64_t ldx, int64_t ldo, const float* gn_part, int part_rows, int groups,
-                                     int rows_per_image, const float* wg, float eps, float* ln_out, int dtype, void* stream) {
-    if (!gn_part || !wg || (reinterpret_cast<uintptr_t>(gn_part) & 15) || (reinterpret_cast<uintptr_t>(wg) & 3)) return DSC_ERR_BAD_ARG;
-    if (!dsc_linear_gnfold_tile_rows(M, N, K, rows_per_image, groups)) return DSC_ERR_UNSUPPORTED;
-    const GfArgs gf{gn_part, wg, part_rows, groups, rows_per_image, eps};
-    return linear_impl(x, w, bias, nullptr, out, M, N, K, ldx, 0, ldo, 0, nullptr, 0, nullptr, 0.f, ln_out, dtype, stream,
-                       nullptr, 0, 0, 1, nullptr, nullptr, &gf);
 }
 
 // K tiles per split: as many splits as bring the grid to ~512 workgroups, at least 8 K tiles each

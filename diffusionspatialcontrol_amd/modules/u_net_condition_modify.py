@@ -527,24 +527,13 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, encoder_hidden_states, cross_attention_kwargs):
         b, c, h, w = x.shape
+        t = _tokens(self.norm(x))                               # channels-last: the token view is free
         w_in = self.proj_in.weight.flatten(1)
         st = None
-        part = ops.gn_partials_of(x) if x.is_contiguous(memory_format=torch.channels_last) else None
-        if part is not None and part.groups == self.norm.num_groups and ops.linear_gnfold_covers(_tokens(x), part, w_in):
-            # the producer of x emitted its group sums: the GroupNorm disappears into proj_in (dsc_linear_gnfold_f16)
-            n = self.norm
-            w2, b2, wg = _derived(self, "gnfold_in", (self.proj_in.weight, self.proj_in.bias, n.weight, n.bias),
-                                  lambda: ops.fold_groupnorm(w_in, self.proj_in.bias, n.weight, n.bias, n.num_groups))
-            want = ops.USE_LN_FOLD and ops.linear_kernel_covers(b * h * w, c, c, x.dtype)
-            t = ops.linear_gnfold(_tokens(x), part, w2, b2, wg, n.eps, ln_stats=want)
-            if want:
-                t, st = t
+        if ops.USE_LN_FOLD and t.is_cuda and ops.linear_kernel_covers(t.shape[0] * t.shape[1], c, c, t.dtype):
+            t, st = ops.linear_ln(t, w_in, self.proj_in.bias, ln_stats=True)   # row statistics for the first block's norm1
         else:
-            t = _tokens(self.norm(x))                           # channels-last: the token view is free
-            if ops.USE_LN_FOLD and t.is_cuda and ops.linear_kernel_covers(t.shape[0] * t.shape[1], c, c, t.dtype):
-                t, st = ops.linear_ln(t, w_in, self.proj_in.bias, ln_stats=True)   # row statistics for the first block's norm1
-            else:
-                t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
+            t = self.proj_in(t) if self.use_linear_projection else self.proj_in.tokens(t)
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, encoder_hidden_states, cross_attention_kwargs, stats=st if i == 0 else None)
         res = _tokens(x)

@@ -459,55 +459,6 @@ def linear_gn(x, weight, bias, residual, rows_per_image, groups):
     return out.reshape(B, L, N), GnPartials(part, rows, groups, N, B, L)
 
 
-USE_GN_FOLD = os.environ.get("DSC_GN_FOLD", "1") != "0"      # Transformer2DModel's GroupNorm folded into its proj_in GEMM (A/B switch)
-
-
-def fold_groupnorm(weight, bias, gamma, beta, groups):
-    """(w', b', wg) for dsc_linear_gnfold_f16: GroupNorm(x; gamma, beta) @ weight.T + bias
-       == ((x - mu) rstd) @ w'.T + b'   with w' = weight * gamma (fp16), b' = bias + weight @ beta (fp16), and
-    wg[n, g] = the sum of the fp16-rounded w'[n, :] over group g's channels (fp32): what the kernel needs to return the fp16
-    rounding of the group means."""
-    N, K = weight.shape
-    w2 = (weight.float() * gamma.float()[None, :]).to(weight.dtype).contiguous()
-    b2 = weight.float() @ beta.float()
-    if bias is not None:
-        b2 = b2 + bias.float()
-    wg = w2.float().reshape(N, groups, K // groups).sum(-1).contiguous()
-    return w2, b2.to(weight.dtype).contiguous(), wg
-
-
-def linear_gnfold_covers(x, part, weight):
-    """True when dsc_linear_gnfold_f16 takes x [B, L, K] (token-major, un-normalised, carrying its producer's partial sums `part`)
-    by weight [N, K]"""
-    if not (USE_GN_FOLD and USE_DSC_GEMM and part is not None and x.is_cuda and x.dim() == 3 and x.dtype == torch.float16
-            and weight.dtype == torch.float16):
-        return False
-    B, L, K = x.shape
-    N = weight.shape[0]
-    if part.groups != 32 or part.C != K or part.B != B or part.hw != L or not _gemm_rows_k_preferred(B * L, K):
-        return False
-    if x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(0) != L * x.stride(1) or x.data_ptr() % 16 != 0:
-        return False
-    return int(_lib.load_library().dsc_linear_gnfold_tile_rows(B * L, N, K, L, 32)) > 0
-
-
-def linear_gnfold(x, part, w2, b2, wg, eps, ln_stats=False):
-    """dsc_linear_gnfold_f16: GroupNorm (32 groups, statistics from `part`) + projection of x [B, L, K] in one launch; w2 / b2 / wg
-    from fold_groupnorm().  ln_stats=True additionally returns the [M, N/64, 2] row partials of the output.  Call only when
-    linear_gnfold_covers() says so."""
-    _require_gpu(x, w2)
-    B, L, K = x.shape
-    N = w2.shape[0]
-    M = B * L
-    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=x.device) if ln_stats else None
-    rc = _lib.load_library().dsc_linear_gnfold_f16(_p(x), _p(w2), _p(b2), _p(out), M, N, K, x.stride(1), N, _p(part.buf), part.rows,
-                                                   32, L, _p(wg), float(eps), _p(stats), 0, _stream_ptr(x))
-    _lib.check(rc, "dsc_linear_gnfold_f16")
-    out = out.reshape(B, L, N)
-    return (out, stats) if ln_stats else out
-
-
 USE_RESIDUAL_WRAP = os.environ.get("DSC_RESIDUAL_WRAP", "1") != "0"   # (A/B switch: 0 = repeat a shorter residual on the host, as before)
 
 

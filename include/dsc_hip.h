@@ -435,25 +435,6 @@ int dsc_groupnorm_apply_nhwc(const void* x, void* y, const void* gamma, const vo
                              void* stream);
 
 /*
- * The GroupNorm in FRONT of a projection folded into it - Transformer2DModel's `norm` -> `proj_in` (the diffusers block that
- * modules/u_net_condition_modify.py:1212-1301 instantiates 16 times: GroupNorm(32, C, eps 1e-6, no activation) then a 1x1
- * convolution / Linear over the channels): one launch instead of GroupNorm + GEMM, and the normalised tensor never exists.
- *   out[m, n] = sum_k w[n, k] * fp16((x[m, k] - m16[b, g(k)]) * r16[b, g(k)]) - colb[b, n] + bias[n]
- * x fp16 [B * rows_per_image, K] token-major (channels-last pixels), UN-normalised, with the partial sums its producer emitted
- * (gn_part fp32 [B][part_rows][32][2][2], as for dsc_groupnorm_apply_nhwc); w = W diag(gamma) (fp16), bias = b + W beta (fp16),
- * wg fp32 [N][32] = per-group row sums of w - all three prepared once per weight by the caller.  m16 / r16 are the fp16 roundings
- * of the group's mean and 1/sqrt(var + eps) (fp64 from the partial sums, in dsc_groupnorm_apply_nhwc's order); the x fragments are
- * centred and scaled in packed fp16 on their way into the MFMA (the difference of two fp16 values that close is exact or rounds
- * relative to the difference: no mean / std amplification), and colb[b, n] = sum_g (mu - m16) r16 wg[n, g] returns what the
- * rounding of the mean left.  ln_out (optional) as in dsc_linear_ln_f16.  groups == 32, K % 64 == 0, K <= 2560, N % 64 == 0;
- * rows_per_image must be a multiple of dsc_linear_gnfold_tile_rows(...) (64 or 128; 0 = shape not covered).
- */
-int dsc_linear_gnfold_tile_rows(int64_t M, int N, int K, int rows_per_image, int groups);
-int dsc_linear_gnfold_f16(const void* x, const void* w, const void* bias, void* out, int64_t M, int N, int K, int64_t ldx,
-                          int64_t ldo, const float* gn_part, int part_rows, int groups, int rows_per_image, const float* wg,
-                          float eps, float* ln_out, int dtype, void* stream);
-
-/*
  * Split-K form of dsc_linear_f16 for few-row, long-K projections - out = x . w^T (+ bias) (+ residual) - the feed-forward
  * output projections (`ff.net.2`, K = 4C) and the 1x1 `conv_shortcut`s on concatenated skips (K = 1920 / 2560) of the 16x16 and
  * 8x8 UNet levels that modules/u_net_condition_modify.py builds from diffusers blocks (M = 128 / 512 token rows at batch 1).

@@ -143,16 +143,6 @@ def test_groupnorm_partial_sums_need_two_channels_per_group(lib):
     assert lib.dsc_conv3x3_gn_rows(2, 64, 64, 320, 320, 32, 0) > 0
 
 
-def test_gnfold_planning(lib):
-    """dsc_linear_gnfold_tile_rows: 32 groups only, whole row tiles per image, K within the kernel's LDS vectors (host-side, no GPU)"""
-    assert lib.dsc_linear_gnfold_tile_rows(4096, 320, 320, 4096, 32) == 64
-    assert lib.dsc_linear_gnfold_tile_rows(65536, 320, 320, 4096, 32) == 128
-    assert lib.dsc_linear_gnfold_tile_rows(4096, 320, 320, 4096, 16) == 0            # groups
-    assert lib.dsc_linear_gnfold_tile_rows(4096, 320, 320, 1000, 32) == 0            # M % rows_per_image
-    assert lib.dsc_linear_gnfold_tile_rows(8192, 320, 5120, 4096, 32) == 0           # K
-    assert lib.dsc_linear_gnfold_tile_rows(16 * 4096, 320, 320, 64, 32) == 0         # a 128-row tile would span two images
-
-
 def test_default_build_does_not_link_hipblaslt(lib):
     """the hipBLASLt fallback is a build option (DSC_WITH_HIPBLASLT=1): the default library neither links it nor claims it, and
     its entry point declines instead of launching"""

@@ -1868,81 +1868,6 @@ def test_groupnorm_epilogue_statistics_with_a_large_channel_offset(ops, offset):
         (e1.max().item(), e2.max().item(), e1.mean().item(), e2.mean().item())
 
 
-@pytest.mark.parametrize("B,hw,C,N,offset", [(1, 64, 320, 320, 0.5), (2, 64, 320, 320, 8.0), (2, 32, 640, 640, 0.5), (1, 32, 640, 640, 30.0),
-                                             (16, 64, 320, 320, 1.0), (3, 32, 320, 640, 2.0)])
-def test_groupnorm_folded_into_the_projection(ops, B, hw, C, N, offset):
-    """dsc_linear_gnfold_f16: Transformer2DModel's GroupNorm (32 groups, eps 1e-6, no activation) + proj_in in one launch, from the
-    partial sums the producing convolution emitted - against fp32 group_norm -> linear, and no worse than the two-launch product
-    path (GroupNorm kernel -> GEMM) even when half of the groups sit `offset` standard deviations from zero; every tile form of the
-    kernel gives the same bytes; the row statistics for the next folded LayerNorm describe what was stored."""
-    from diffusionspatialcontrol_amd import _lib
-    lib = _lib.load_library()
-    g = torch.Generator().manual_seed(B * hw + C + N)
-    cl = torch.channels_last
-    x0 = (torch.randn(B, C, hw, hw, generator=g) * 0.7).half().cuda().contiguous(memory_format=cl)
-    w3 = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).half().cuda().contiguous(memory_format=cl)
-    b3 = torch.randn(C, generator=g) * 0.2
-    b3[: C // 2] += offset * 0.7
-    if ops.conv3x3_gn_rows(x0, w3, 32) == 0:
-        pytest.skip("the producing convolution emits no partial sums at this shape")
-    x = ops.conv3x3_gn(x0, w3, 32, bias=b3.half().cuda())
-    part = ops.gn_partials_of(x)
-    gamma = (1 + 0.2 * torch.randn(C, generator=g)).half().cuda()
-    beta = (0.2 * torch.randn(C, generator=g)).half().cuda()
-    W = (torch.randn(N, C, generator=g) / math.sqrt(C)).half().cuda()
-    bias = (torch.randn(N, generator=g) * 0.2).half().cuda()
-    t = x.permute(0, 2, 3, 1).reshape(B, hw * hw, C)
-    assert ops.linear_gnfold_covers(t, part, W)
-    ref = F.group_norm(x.float(), 32, gamma.float(), beta.float(), 1e-6).permute(0, 2, 3, 1).reshape(B, hw * hw, C) @ W.float().t() + bias.float()
-    h = ops.groupnorm_apply_nhwc(x, part, 32, gamma, beta, 1e-6, False)
-    y0 = ops.linear(h.permute(0, 2, 3, 1).reshape(B, hw * hw, C), W, bias)
-    w2, b2, wg = ops.fold_groupnorm(W, bias, gamma, beta, 32)
-    y, st = ops.linear_gnfold(t, part, w2, b2, wg, 1e-6, ln_stats=True)
-    e1, e0 = (y.float() - ref).abs(), (y0.float() - ref).abs()
-    assert torch.isfinite(y).all()
-    assert e1.max().item() <= 1.5 * e0.max().item() + 4e-3 and e1.mean().item() <= 1.5 * e0.mean().item() + 2e-4, \
-        (e1.max().item(), e0.max().item(), e1.mean().item(), e0.mean().item())
-    yf = y.float().reshape(B * hw * hw, N)
-    assert torch.allclose(st[..., 0].sum(1), yf.sum(1), rtol=1e-5, atol=2e-3)
-    assert torch.allclose(st[..., 1].sum(1), (yf * yf).sum(1), rtol=1e-5, atol=2e-2)
-    assert torch.equal(ops.linear_gnfold(t, part, w2, b2, wg, 1e-6), y)
-    try:
-        for knob in (643, 642, 1282, 1283, 40643, 90643):
-            lib.dsc_debug_set_gemm_stages(knob)
-            if int(lib.dsc_linear_gnfold_tile_rows(B * hw * hw, N, C, hw * hw, 32)) == 0:
-                continue
-            assert torch.equal(ops.linear_gnfold(t, part, w2, b2, wg, 1e-6), y), knob
-    finally:
-        lib.dsc_debug_set_gemm_stages(0)
-
-
-def test_transformer_groupnorm_fold_equals_the_unfolded_block(ops):
-    """Transformer2DModel with its GroupNorm folded into proj_in (the default when the input carries partial sums) against the
-    same module with DSC_GN_FOLD off: same function to fp16 rounding, and the folded path really ran (no GroupNorm launch)."""
-    from diffusionspatialcontrol_amd.modules import u_net_condition_modify as U
-    torch.manual_seed(5)
-    m = U.Transformer2DModel(320, 8, 1, 768, 32, False).half().cuda().eval()
-    cl = torch.channels_last
-    x0 = (torch.randn(2, 320, 32, 32) * 0.7).half().cuda().contiguous(memory_format=cl)
-    w3 = (torch.randn(320, 320, 3, 3) / math.sqrt(9 * 320)).half().cuda().contiguous(memory_format=cl)
-    x = ops.conv3x3_gn(x0, w3, 32)
-    ehs = torch.randn(2, 77, 768).half().cuda()
-    calls = []
-    real = ops.linear_gnfold
-    ops.linear_gnfold = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
-    try:
-        with torch.no_grad():
-            y1 = m(x, ehs, None)
-            assert calls, "the folded path did not run"
-            ops.USE_GN_FOLD = False
-            y0 = m(x, ehs, None)
-    finally:
-        ops.USE_GN_FOLD = True
-        ops.linear_gnfold = real
-    d = (y1.float() - y0.float()).abs()
-    assert d.max().item() < 3e-2 * max(1.0, y0.float().abs().max().item()) and d.mean().item() < 2e-3, (d.max().item(), d.mean().item())
-
-
 @pytest.mark.parametrize("B,L,K,N,groups", [(2, 4096, 320, 320, 32), (2, 1024, 640, 640, 32), (2, 4096, 960, 320, 32), (2, 1024, 1920, 640, 32),
                                             (4, 256, 128, 64, 4)])
 def test_groupnorm_statistics_from_the_gemm_epilogue(ops, B, L, K, N, groups):
