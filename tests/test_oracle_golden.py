@@ -235,6 +235,29 @@ def test_resize_block_aligned_is_kernel_independent():
         np.testing.assert_array_equal(out, exp)
 
 
+def test_resize_cubic_against_an_independent_implementation():
+    """OpenCV is absent, so `resize_cubic_u8` (Keys kernel a = -0.75, half-pixel centres, replicated border, no antialias) stays
+    parity unpinned against cv2 itself; torch's bicubic interpolate is an INDEPENDENT implementation of the same published kernel
+    and conventions, and must give the same pixels up to the last rounding: arbitrary (non-aligned) sizes, down- and upscaling.
+    (What this cannot see: OpenCV's uint8 path rounds the four coefficients to 11-bit fixed point; for the sizes the pipeline
+    produces from multiples of 64 px every sampling offset is x.5 and those coefficients are exact.)"""
+    rng = np.random.default_rng(11)
+    for (H, W, h_r, w_r) in ((512, 512, 64, 64), (516, 500, 65, 63), (96, 80, 37, 52), (40, 56, 96, 120), (768, 512, 96, 64)):
+        img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+        got = re_.resize_cubic_u8(img, (w_r, h_r)).astype(np.int64)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img).double()[None, None], size=(h_r, w_r), mode="bicubic", align_corners=False)[0, 0]
+        ref = torch.clamp(torch.floor(ref + 0.5), 0, 255).numpy().astype(np.int64)
+        diff = np.abs(got - ref)
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-3, (H, W, h_r, w_r, diff.max(), (diff != 0).mean())
+    # binary masks (what the encoder resizes): identical after the encoder's own binarisation at the maximum
+    m = (rng.random((516, 500)) < 0.5).astype(np.uint8)
+    m = np.kron(m[::12, ::10][:43, :50], np.ones((12, 10), dtype=np.uint8))
+    got = re_.resize_cubic_u8(m, (63, 65))
+    ref = torch.nn.functional.interpolate(torch.from_numpy(m).double()[None, None], size=(65, 63), mode="bicubic", align_corners=False)[0, 0]
+    ref = torch.clamp(torch.floor(ref + 0.5), 0, 255).numpy().astype(np.uint8)
+    assert (got != ref).mean() < 2e-3
+
+
 def test_denoiser():
     g = load("denoiser.npz")
     den = kd.DiscreteEpsDenoiser(kd.sd15_alphas_cumprod())
